@@ -1,0 +1,236 @@
+/*
+ * neptune_hip.h -- C ABI of the MI355X (gfx950) backend for NeptuneIR's stencil hot path.
+ *
+ * This is the drop-in boundary.  Everything a host program (emitted host C++, the Python
+ * frontend through ctypes, a PETSc MatMult thunk, the bench) needs is reachable through
+ * the plain-C entry points below: plain pointers and sizes, no C++ or torch types.
+ *
+ * The reference project (levia-than/neptune-pde-solver) lowers `neptune_ir.apply` & co to
+ * scalar CPU loop nests (lib/Passes/DataflowLowering.cpp:258-448).  The entry points here
+ * are what a `backend=hip` variant of that lowering calls instead.  Each declaration cites
+ * the reference construct it replaces.
+ *
+ * Error convention: like the reference runtime (NeptunePETScRuntime.cpp:15-30), ABI
+ * functions that cannot report an error print "[NeptuneRT][HIP] ..." to stderr and abort().
+ * Functions returning `int` return 0 on success and a negative NEPTUNE_HIP_E* code when the
+ * request is rejected before anything is launched (bad geometry, unsupported shape).
+ */
+#ifndef NEPTUNE_HIP_H
+#define NEPTUNE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------
+ * 1. memref descriptors of lowered functions
+ *    Same field order as the reference's MLIR->LLVM memref ABI
+ *    (include/Runtime/PETSc/NeptunePETScRuntime.h:22-42; rank 3 added the same way).
+ *    A rank-r memref *argument* is passed expanded:
+ *      (void* allocated, void* aligned, int64 offset, int64 size[0..r), int64 stride[0..r))
+ *    and a memref *result* is returned as the struct by value
+ *    (driver prototype: test/smoke_tests/smoke_apply.sh:39-50).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[1];
+  int64_t strides[1];
+} NeptuneMemRef1D;
+
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[2];
+  int64_t strides[2];
+} NeptuneMemRef2D;
+
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[3];
+  int64_t strides[3];
+} NeptuneMemRef3D;
+
+/* ------------------------------------------------------------------------------------
+ * 2. constants
+ * ---------------------------------------------------------------------------------- */
+#define NEPTUNE_HIP_MAX_RANK 3
+#define NEPTUNE_HIP_MAX_INPUTS 4
+
+#define NEPTUNE_HIP_OK 0
+#define NEPTUNE_HIP_EINVAL (-1)      /* malformed geometry / null pointer            */
+#define NEPTUNE_HIP_EUNSUPPORTED (-2) /* valid request this build cannot serve         */
+#define NEPTUNE_HIP_EOOB (-3)        /* an access would leave its input's box (UB in the
+                                        reference, DataflowLowering.cpp:382-410: no
+                                        bounds check; rejected here at plan time)      */
+
+/* element types (the `element =` of !neptune_ir.field / !neptune_ir.temp,
+ * include/Dialect/NeptuneIR/NeptuneIRTypes.td:22-33) */
+#define NEPTUNE_HIP_F64 0
+#define NEPTUNE_HIP_F32 1
+
+/* kernel selection for neptune_hip_launch_cfg_t.kernel */
+#define NEPTUNE_HIP_KERNEL_AUTO 0
+#define NEPTUNE_HIP_KERNEL_DIRECT 1 /* one thread per cell, neighbours through L1/L2   */
+#define NEPTUNE_HIP_KERNEL_MARCH 2  /* wave tiles marching along dim 0, planes in VGPRs */
+
+/* built-in stencil bodies; each one is the body of a committed fixture
+ * (tests/fixtures/mlir/...) evaluated in that file's textual op order */
+#define NEPTUNE_HIP_BODY_LAP2D5_F64 0  /* apply-2d-5pt.mlir   */
+#define NEPTUNE_HIP_BODY_LAP3D7_F64 1  /* apply-3d-7pt.mlir   */
+#define NEPTUNE_HIP_BODY_LAP3D27_F32 2 /* apply-3d-27pt.mlir  */
+#define NEPTUNE_HIP_BODY_LAP1D3_F64 3  /* @ac_lap of the reference's smoke_time_advance.mlir:13-29 */
+#define NEPTUNE_HIP_BODY_COUNT 4
+
+/* ------------------------------------------------------------------------------------
+ * 3. geometry of one `neptune_ir.apply`
+ *    (include/Dialect/NeptuneIR/NeptuneIROps.td:164-197; semantics
+ *     lib/Passes/DataflowLowering.cpp:258-448)
+ *
+ *    All boxes are half-open logical boxes [lb, ub) as in #neptune_ir.bounds
+ *    (NeptuneIRAttrs.td:9-26).  A temp with box [lb,ub) is a dense row-major buffer of
+ *    shape ub-lb (DataflowLowering.cpp:41-49); logical point p lives at physical index
+ *    p - lb.  The result has box [out_lb,out_ub); input k has box [in_lb[k],in_ub[k]).
+ *    shape(input 0) must equal shape(result) (cast at DataflowLowering.cpp:285-286).
+ *
+ *    result[q]      = input0[q]                       for every physical q   (copy-through, :283-287)
+ *    result<p>      = body(p; access(k,off) = input_k<p+off>)  for p in [lb,ub)  (:289-444)
+ *
+ *    region: physical sub-box (result coordinates) this launch is responsible for; cells
+ *    outside are not touched.  Whole field: region_lb = 0, region_ub = shape.  Used by the
+ *    slab decomposition to split one apply into edge planes + interior.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t rank;       /* 1..NEPTUNE_HIP_MAX_RANK */
+  int32_t num_inputs; /* 1..NEPTUNE_HIP_MAX_INPUTS */
+  int64_t out_lb[NEPTUNE_HIP_MAX_RANK], out_ub[NEPTUNE_HIP_MAX_RANK];
+  int64_t lb[NEPTUNE_HIP_MAX_RANK], ub[NEPTUNE_HIP_MAX_RANK]; /* apply.bounds */
+  int64_t in_lb[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK];
+  int64_t in_ub[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK];
+  int64_t region_lb[NEPTUNE_HIP_MAX_RANK], region_ub[NEPTUNE_HIP_MAX_RANK];
+} neptune_hip_apply_geom_t;
+
+/* launch tuning; zero-initialised = defaults */
+typedef struct {
+  int32_t kernel;   /* NEPTUNE_HIP_KERNEL_* */
+  int32_t variant;  /* march tile variant, 0 = default; see neptune_hip_march_variant_name */
+  int32_t chunk;    /* march: planes per workgroup along dim 0, 0 = auto */
+  int32_t flags;    /* reserved, must be 0 */
+} neptune_hip_launch_cfg_t;
+
+/* ------------------------------------------------------------------------------------
+ * 4. runtime: device, memory, streams
+ *    The reference allocates results with malloc (memref.alloc, DataflowLowering.cpp:281)
+ *    and lets the caller free() them (NeptunePETScRuntime.cpp:219-221).  Device-resident
+ *    buffers follow the same callee-allocates / caller-frees rule through
+ *    neptune_hip_malloc / neptune_rt_free.
+ * ---------------------------------------------------------------------------------- */
+/* Select the HIP device for this process (one process per GPU).  Idempotent. */
+void neptune_hip_init(int device);
+/* Release cached workspaces.  Safe to call more than once. */
+void neptune_hip_finalize(void);
+/* 1 when a HIP device is usable, 0 otherwise (never aborts). */
+int neptune_hip_available(void);
+/* e.g. "gfx950:sramecc+:xnack-"; pointer valid for the process lifetime */
+const char *neptune_hip_arch(void);
+int neptune_hip_cu_count(void);
+const char *neptune_hip_version(void);
+
+void *neptune_hip_malloc(size_t bytes);
+void neptune_hip_free(void *dptr);
+void neptune_hip_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream);
+void neptune_hip_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream);
+void neptune_hip_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream);
+void neptune_hip_stream_sync(void *stream);
+void neptune_hip_device_sync(void);
+/* 1 if p is device (hipMalloc) memory, 0 if host/unknown */
+int neptune_hip_is_device_ptr(const void *p);
+
+/* replaces the reference's neptune_rt_free (NeptunePETScRuntime.cpp:1825 -> free()):
+ * frees either a malloc'ed host result or a device result of a lowered function */
+void neptune_rt_free(void *p);
+
+/* ------------------------------------------------------------------------------------
+ * 5. the hot path: apply
+ * ---------------------------------------------------------------------------------- */
+/* Validate a geometry against a footprint (max |offset| per input and dim): every access
+ * of every in-bounds point must stay inside its input's box.  Returns NEPTUNE_HIP_OK,
+ * NEPTUNE_HIP_EINVAL or NEPTUNE_HIP_EOOB.  radius[k][d] = max |offset| of input k, dim d. */
+int neptune_hip_check_geom(const neptune_hip_apply_geom_t *g,
+                           const int32_t radius[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK]);
+
+/* Launch one built-in body over `g` on `stream` (a hipStream_t, NULL = default stream).
+ * in[k], out are DEVICE pointers to dense row-major buffers of the shapes `g` implies.
+ * out must not overlap any input.  Asynchronous.
+ * Replaces: the scf.for nest of ApplyToSCFForLowering (DataflowLowering.cpp:289-444)
+ * plus its copy-through memref.copy (:283-287), for the body of the named fixture. */
+int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t *g,
+                              const void *const *in, void *out, void *stream,
+                              const neptune_hip_launch_cfg_t *cfg);
+
+/* Which kernel neptune_hip_apply_builtin would run for (body, g, cfg):
+ * NEPTUNE_HIP_KERNEL_DIRECT / _MARCH, or a negative error. */
+int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t *g,
+                                   const void *const *in, const void *out,
+                                   const neptune_hip_launch_cfg_t *cfg);
+
+/* Name of the device kernel (as rocprofv3 lists it, without template arguments) that the
+ * plan above launches; pointer valid for the process lifetime. */
+const char *neptune_hip_kernel_name(int kernel);
+/* march tile variants compiled into the library, per field rank (2 or 3) */
+int neptune_hip_march_variant_count(int rank);
+const char *neptune_hip_march_variant_name(int rank, int variant);
+
+/* ------------------------------------------------------------------------------------
+ * 6. store (lib/Passes/DataflowLowering.cpp:165-220)
+ *    no bounds : whole-buffer copy (memref.copy, :176-179)
+ *    bounds    : logical box [lb,ub) copied between two buffers that each use their own
+ *                logical origin (:184-217)
+ * ---------------------------------------------------------------------------------- */
+int neptune_hip_store_full(int dtype, const void *src, void *dst, int64_t count, void *stream);
+int neptune_hip_store_box(int dtype, int rank, const void *src, const int64_t *src_lb,
+                          const int64_t *src_ub, void *dst, const int64_t *dst_lb,
+                          const int64_t *dst_ub, const int64_t *lb, const int64_t *ub,
+                          void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * 7. helpers for tests and the bench (device-side, so 8 GiB fields never cross PCIe)
+ * ---------------------------------------------------------------------------------- */
+/* Deterministic field: value depends only on (global linear index + index_offset, seed);
+ * integer hash mapped exactly to [-1,1) -- the same bits on host and device
+ * (host twin: neptune_hip_hash_value). */
+int neptune_hip_fill_hash(int dtype, void *dst, int64_t count, int64_t index_offset,
+                          uint64_t seed, void *stream);
+double neptune_hip_hash_value(int dtype, int64_t index, uint64_t seed);
+/* Number of elements whose bit patterns differ between two device buffers (blocking). */
+int64_t neptune_hip_count_mismatch(int dtype, const void *a, const void *b, int64_t count,
+                                   void *stream);
+/* Time `reps` launches of one built-in apply with HIP events on `stream`; returns the
+ * average milliseconds per launch (blocking).  in/out as in neptune_hip_apply_builtin. */
+double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t *g,
+                                      const void *const *in, void *out, void *stream,
+                                      const neptune_hip_launch_cfg_t *cfg, int warmup, int reps);
+/* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling. */
+double neptune_hip_time_copy(void *dst, const void *src, size_t bytes, void *stream, int warmup,
+                             int reps);
+
+/* HIP events for callers that time a stream themselves (bench.py). */
+void *neptune_hip_event_create(void);
+void neptune_hip_event_destroy(void *ev);
+void neptune_hip_event_record(void *ev, void *stream);
+void neptune_hip_event_sync(void *ev);
+double neptune_hip_event_elapsed_ms(void *start, void *stop);
+/* make `stream` wait for `ev` (stream-to-stream ordering without blocking the host) */
+void neptune_hip_stream_wait_event(void *stream, void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEPTUNE_HIP_H */

@@ -1,0 +1,323 @@
+// apply_launch.hpp -- host side of one `neptune_ir.apply`: validate the geometry, choose a
+// kernel, fill its parameters, hipLaunchKernelGGL.  Shared by the runtime library (built-in
+// bodies) and by every module the lowering emits (generated bodies).
+//
+// Plan rules (all decided on the host, before anything runs on the device):
+//   * geometry must be well formed and every access of every in-bounds point must stay inside
+//     its input's box -- the reference performs no check there and reads out of bounds
+//     (lib/Passes/DataflowLowering.cpp:380-410; test/smoke_tests/smoke_apply.mlir:4-9 does);
+//     this backend refuses such a plan instead of emulating undefined behaviour.
+//   * march kernel when: footprint allows it, rank >= 2, all inputs share the result's box,
+//     the contiguous extent is a multiple of the 16-byte lane vector and at least one wave
+//     wide, all base pointers are 16-byte aligned, and the region only restricts dim 0.
+//   * otherwise the direct kernel.
+#pragma once
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../../include/neptune_hip.h"
+#include "apply_common.hpp"
+#include "apply_direct.hpp"
+#include "apply_march.hpp"
+
+#ifndef NEPTUNE_HIP_FULL_VARIANTS
+#define NEPTUNE_HIP_FULL_VARIANTS 0  // generated modules compile the default tile only
+#endif
+
+namespace neptune_hip {
+
+#define NEPTUNE_HIP_CHECK(expr)                                                              \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      fprintf(stderr, "[NeptuneRT][HIP] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(_e), \
+              __FILE__, __LINE__);                                                           \
+      abort();                                                                               \
+    }                                                                                        \
+  } while (0)
+
+template <class T> struct DTypeOf;
+template <> struct DTypeOf<double> { static constexpr int value = NEPTUNE_HIP_F64; };
+template <> struct DTypeOf<float> { static constexpr int value = NEPTUNE_HIP_F32; };
+
+// ---- geometry checks ------------------------------------------------------------------
+inline int geom_validate(const neptune_hip_apply_geom_t* g) {
+  if (!g) return NEPTUNE_HIP_EINVAL;
+  if (g->rank < 1 || g->rank > kMaxRank) return NEPTUNE_HIP_EINVAL;
+  if (g->num_inputs < 1 || g->num_inputs > kMaxInputs) return NEPTUNE_HIP_EINVAL;
+  for (int d = 0; d < g->rank; ++d) {
+    const int64_t n = g->out_ub[d] - g->out_lb[d];
+    if (n <= 0) return NEPTUNE_HIP_EINVAL;
+    // result shape must equal input 0's shape (cast at DataflowLowering.cpp:285-286)
+    if (g->in_ub[0][d] - g->in_lb[0][d] != n) return NEPTUNE_HIP_EINVAL;
+    for (int k = 0; k < g->num_inputs; ++k)
+      if (g->in_ub[k][d] - g->in_lb[k][d] <= 0) return NEPTUNE_HIP_EINVAL;
+    if (g->lb[d] > g->ub[d]) return NEPTUNE_HIP_EINVAL;
+    // the yielded scalar is stored at p - out_lb (:427-444): bounds must lie in the result box
+    if (g->lb[d] < g->ub[d] && (g->lb[d] < g->out_lb[d] || g->ub[d] > g->out_ub[d]))
+      return NEPTUNE_HIP_EOOB;
+    if (g->region_lb[d] < 0 || g->region_ub[d] > n || g->region_lb[d] > g->region_ub[d])
+      return NEPTUNE_HIP_EINVAL;
+  }
+  return NEPTUNE_HIP_OK;
+}
+
+inline bool geom_bounds_empty(const neptune_hip_apply_geom_t* g) {
+  for (int d = 0; d < g->rank; ++d)
+    if (g->lb[d] >= g->ub[d]) return true;
+  return false;
+}
+
+inline int geom_check_radius(const neptune_hip_apply_geom_t* g,
+                             const int32_t radius[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK]) {
+  int rc = geom_validate(g);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  if (geom_bounds_empty(g)) return NEPTUNE_HIP_OK;
+  for (int k = 0; k < g->num_inputs; ++k)
+    for (int d = 0; d < g->rank; ++d) {
+      const int64_t r = radius[k][d];
+      if (r < 0) continue;  // input not accessed at all
+      if (g->lb[d] - r < g->in_lb[k][d] || g->ub[d] + r > g->in_ub[k][d]) return NEPTUNE_HIP_EOOB;
+    }
+  return NEPTUNE_HIP_OK;
+}
+
+// logical-dim arrays -> kernel axis order (I,J,K); absent axes get `fill`
+template <int RANK>
+inline void to_axes(const int64_t* src, int64_t dst[3], int64_t fill) {
+  dst[0] = dst[1] = dst[2] = fill;
+  if constexpr (RANK == 3) { dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; }
+  else if constexpr (RANK == 2) { dst[0] = src[0]; dst[2] = src[1]; }
+  else { dst[2] = src[0]; }
+}
+
+// ---- march tile variants --------------------------------------------------------------
+struct MarchVariant {
+  int RJ, WJ, WK;
+  bool dpp, nt;
+  const char* name;
+};
+// rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B
+constexpr MarchVariant kMarch3[] = {
+    {4, 4, 1, false, false, "rj4_wj4_wk1"},
+#if NEPTUNE_HIP_FULL_VARIANTS
+    {4, 1, 4, false, false, "rj4_wj1_wk4"},
+    {2, 4, 1, false, false, "rj2_wj4_wk1"},
+    {2, 2, 2, false, false, "rj2_wj2_wk2"},
+    {8, 2, 1, false, false, "rj8_wj2_wk1"},
+    {1, 4, 1, false, false, "rj1_wj4_wk1"},
+    {4, 4, 1, true, false, "rj4_wj4_wk1_dpp"},
+    {4, 4, 1, false, true, "rj4_wj4_wk1_nt"},
+    {4, 4, 1, true, true, "rj4_wj4_wk1_dpp_nt"},
+    {2, 4, 1, true, true, "rj2_wj4_wk1_dpp_nt"},
+    {4, 2, 2, true, true, "rj4_wj2_wk2_dpp_nt"},
+    {8, 2, 1, true, true, "rj8_wj2_wk1_dpp_nt"},
+#endif
+};
+// rank 2: J has extent 1, a workgroup is WK waves side by side
+constexpr MarchVariant kMarch2[] = {
+    {1, 1, 4, false, false, "wk4"},
+#if NEPTUNE_HIP_FULL_VARIANTS
+    {1, 1, 2, false, false, "wk2"},
+    {1, 1, 1, false, false, "wk1"},
+    {1, 1, 8, false, false, "wk8"},
+    {1, 1, 4, true, false, "wk4_dpp"},
+    {1, 1, 4, false, true, "wk4_nt"},
+    {1, 1, 4, true, true, "wk4_dpp_nt"},
+    {1, 1, 1, true, true, "wk1_dpp_nt"},
+#endif
+};
+constexpr int kNumMarch3 = sizeof(kMarch3) / sizeof(kMarch3[0]);
+constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
+
+inline int march_variant_count(int rank) { return rank == 3 ? kNumMarch3 : (rank == 2 ? kNumMarch2 : 0); }
+inline const MarchVariant* march_variant(int rank, int v) {
+  if (v < 0 || v >= march_variant_count(rank)) return nullptr;
+  return rank == 3 ? &kMarch3[v] : &kMarch2[v];
+}
+
+template <class Body, class T, int RANK, int NIN, class FP, int RJ, int WJ, int WK, bool DPP, bool NT>
+inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk_req,
+                                 hipStream_t stream) {
+  constexpr int VK = 16 / sizeof(T);
+  const int64_t tileK = (int64_t)WK * kWave * VK, tileJ = (int64_t)WJ * RJ;
+  P.nK = (uint32_t)((P.N2 + tileK - 1) / tileK);
+  P.nJ = (uint32_t)((P.N1 + tileJ - 1) / tileJ);
+  const int64_t tilesJK = (int64_t)P.nJ * P.nK;
+  int64_t chunk = chunk_req;
+  if (chunk <= 0) {
+    // aim for ~2 rounds of 16 waves on each of the 256 CUs; a chunk re-reads 2*R0 planes, so
+    // keep it >= 16 planes
+    const int64_t want_blocks = (2 * 16 * 256) / (WJ * WK);
+    const int64_t nI_want = (want_blocks + tilesJK - 1) / tilesJK;
+    chunk = (planes + nI_want - 1) / (nI_want > 0 ? nI_want : 1);
+    if (chunk < 16) chunk = 16;
+  }
+  if (chunk > planes) chunk = planes;
+  const int64_t nI = (planes + chunk - 1) / chunk;
+  const int64_t blocks = nI * tilesJK;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) {
+    fprintf(stderr, "[NeptuneRT][HIP] march grid of %lld workgroups is not launchable\n", (long long)blocks);
+    abort();
+  }
+  P.chunk = (int32_t)chunk;
+  hipLaunchKernelGGL((neptune_apply_march<Body, T, RANK, NIN, FP, RJ, WJ, WK, DPP, NT>), dim3((uint32_t)blocks),
+                     dim3(kWave * WJ * WK), 0, stream, P, body);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+}
+
+template <class Body, class T, int RANK, int NIN, class FP>
+inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
+                         hipStream_t stream) {
+#define NEPTUNE_MV(RJ, WJ, WK, DPP, NT) \
+  launch_march_variant<Body, T, RANK, NIN, FP, RJ, WJ, WK, DPP, NT>(P, body, planes, chunk, stream)
+  if constexpr (RANK == 3) {
+    switch (variant) {
+      default:
+      case 0: NEPTUNE_MV(4, 4, 1, false, false); break;
+#if NEPTUNE_HIP_FULL_VARIANTS
+      case 1: NEPTUNE_MV(4, 1, 4, false, false); break;
+      case 2: NEPTUNE_MV(2, 4, 1, false, false); break;
+      case 3: NEPTUNE_MV(2, 2, 2, false, false); break;
+      case 4: NEPTUNE_MV(8, 2, 1, false, false); break;
+      case 5: NEPTUNE_MV(1, 4, 1, false, false); break;
+      case 6: NEPTUNE_MV(4, 4, 1, true, false); break;
+      case 7: NEPTUNE_MV(4, 4, 1, false, true); break;
+      case 8: NEPTUNE_MV(4, 4, 1, true, true); break;
+      case 9: NEPTUNE_MV(2, 4, 1, true, true); break;
+      case 10: NEPTUNE_MV(4, 2, 2, true, true); break;
+      case 11: NEPTUNE_MV(8, 2, 1, true, true); break;
+#endif
+    }
+  } else {
+    switch (variant) {
+      default:
+      case 0: NEPTUNE_MV(1, 1, 4, false, false); break;
+#if NEPTUNE_HIP_FULL_VARIANTS
+      case 1: NEPTUNE_MV(1, 1, 2, false, false); break;
+      case 2: NEPTUNE_MV(1, 1, 1, false, false); break;
+      case 3: NEPTUNE_MV(1, 1, 8, false, false); break;
+      case 4: NEPTUNE_MV(1, 1, 4, true, false); break;
+      case 5: NEPTUNE_MV(1, 1, 4, false, true); break;
+      case 6: NEPTUNE_MV(1, 1, 4, true, true); break;
+      case 7: NEPTUNE_MV(1, 1, 1, true, true); break;
+#endif
+    }
+  }
+#undef NEPTUNE_MV
+}
+
+// ---- plan + launch ----------------------------------------------------------------------
+template <class T, int RANK, int NIN, class FP>
+inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out,
+                      const neptune_hip_launch_cfg_t* cfg) {
+  constexpr int VK = 16 / sizeof(T);
+  int rc = geom_validate(g);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  if (g->rank != RANK || g->num_inputs != NIN) return NEPTUNE_HIP_EINVAL;
+  if (!in || !out) return NEPTUNE_HIP_EINVAL;
+  for (int k = 0; k < NIN; ++k)
+    if (!in[k]) return NEPTUNE_HIP_EINVAL;
+  const int want = cfg ? cfg->kernel : NEPTUNE_HIP_KERNEL_AUTO;
+  if (want == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_KERNEL_DIRECT;
+
+  bool ok = FP::MARCH_OK && RANK >= 2;
+  const int64_t nK = g->out_ub[RANK - 1] - g->out_lb[RANK - 1];
+  ok = ok && (nK % VK == 0) && nK >= VK;
+  {
+    // in-plane offsets are 32-bit in the march kernel: every extent and one plane's bytes
+    // (everything but dim 0) must stay below 2^31
+    int64_t plane_bytes = (int64_t)sizeof(T);
+    for (int d = 0; d < RANK; ++d) {
+      const int64_t n = g->out_ub[d] - g->out_lb[d];
+      ok = ok && n < 0x7fffffffLL;
+      if (d > 0) plane_bytes *= n;
+    }
+    ok = ok && plane_bytes < 0x7fffffffLL;
+  }
+  for (int k = 0; ok && k < NIN; ++k) {
+    for (int d = 0; d < RANK; ++d)
+      ok = ok && g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d];
+    ok = ok && ((uintptr_t)in[k] % 16 == 0);
+  }
+  ok = ok && ((uintptr_t)out % 16 == 0);
+  for (int d = 1; ok && d < RANK; ++d)
+    ok = ok && g->region_lb[d] == 0 && g->region_ub[d] == g->out_ub[d] - g->out_lb[d];
+  if (want == NEPTUNE_HIP_KERNEL_MARCH) return ok ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_EUNSUPPORTED;
+  // auto: the march kernel pays off once a row fills at least one wave
+  if (ok && nK >= (int64_t)kWave * VK) return NEPTUNE_HIP_KERNEL_MARCH;
+  return NEPTUNE_HIP_KERNEL_DIRECT;
+}
+
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                        hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+  const int kernel = plan_apply<T, RANK, NIN, FP>(g, in, out, cfg);
+  if (kernel < 0) return kernel;
+  for (int d = 0; d < RANK; ++d)
+    if (g->region_lb[d] == g->region_ub[d]) return NEPTUNE_HIP_OK;  // empty region: nothing to do
+
+  if constexpr (FP::MARCH_OK && RANK >= 2) if (kernel == NEPTUNE_HIP_KERNEL_MARCH) {
+    MarchParams<T, NIN> P{};
+    for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
+    P.out = static_cast<T*>(out);
+    int64_t shape[3], plb[3], pub[3], n[3], a_lb[3], a_ub[3], rlb[3], rub[3];
+    for (int d = 0; d < RANK; ++d) {
+      shape[d] = g->out_ub[d] - g->out_lb[d];
+      plb[d] = g->lb[d] - g->out_lb[d];  // result-physical bounds
+      pub[d] = g->ub[d] - g->out_lb[d];
+    }
+    to_axes<RANK>(shape, n, 1);
+    to_axes<RANK>(plb, a_lb, 0);
+    to_axes<RANK>(pub, a_ub, 1);
+    P.N0 = (int32_t)n[0]; P.N1 = (int32_t)n[1]; P.N2 = (int32_t)n[2];
+    for (int a = 0; a < 3; ++a) {
+      // clamp into [0, extent] so the int32 narrowing is exact (empty bounds stay empty)
+      const int64_t lo = a_lb[a] < 0 ? 0 : (a_lb[a] > n[a] ? n[a] : a_lb[a]);
+      const int64_t hi = a_ub[a] < 0 ? 0 : (a_ub[a] > n[a] ? n[a] : a_ub[a]);
+      P.plb[a] = (int32_t)lo;
+      P.pub[a] = (int32_t)hi;
+    }
+    to_axes<RANK>(g->out_lb, P.olb, 0);
+    to_axes<RANK>(g->region_lb, rlb, 0);
+    to_axes<RANK>(g->region_ub, rub, 1);
+    P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];
+    int variant = cfg ? cfg->variant : 0;
+    if (variant < 0 || variant >= march_variant_count(RANK)) variant = 0;
+    launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
+    return NEPTUNE_HIP_OK;
+  }
+
+  DirectParams<T, NIN> P{};
+  for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
+  P.out = static_cast<T*>(out);
+  int64_t shape[3];
+  for (int d = 0; d < RANK; ++d) shape[d] = g->out_ub[d] - g->out_lb[d];
+  to_axes<RANK>(shape, P.n, 1);
+  to_axes<RANK>(g->out_lb, P.olb, 0);
+  to_axes<RANK>(g->lb, P.lb, 0);
+  to_axes<RANK>(g->ub, P.ub, 1);
+  to_axes<RANK>(g->region_lb, P.rlb, 0);
+  to_axes<RANK>(g->region_ub, P.rub, 1);
+  for (int k = 0; k < NIN; ++k) {
+    int64_t m[3], sh[3];
+    for (int d = 0; d < RANK; ++d) {
+      m[d] = g->in_ub[k][d] - g->in_lb[k][d];
+      sh[d] = g->out_lb[d] - g->in_lb[k][d];
+    }
+    to_axes<RANK>(m, P.m[k], 1);
+    to_axes<RANK>(sh, P.sh[k], 0);
+  }
+  const int64_t total = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * (P.rub[2] - P.rlb[2]);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) {
+    fprintf(stderr, "[NeptuneRT][HIP] direct grid of %lld workgroups is not launchable\n", (long long)blocks);
+    abort();
+  }
+  hipLaunchKernelGGL((neptune_apply_direct<Body, T, RANK, NIN>), dim3((uint32_t)blocks), dim3(256), 0, stream, P,
+                     body);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
+}  // namespace neptune_hip

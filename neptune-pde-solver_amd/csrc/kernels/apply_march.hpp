@@ -1,0 +1,377 @@
+// apply_march.hpp -- the MI355X stencil kernel for `neptune_ir.apply`: wave tiles that march
+// along the slowest axis with the neighbourhood held in registers.
+//
+// What the reference does for this op (lib/Passes/DataflowLowering.cpp:258-448): malloc the
+// result, memcpy input 0 into it (copy-through), then a scalar loop nest that reloads every
+// neighbour from memory.  Here one kernel does all of it in a single pass over HBM:
+//
+//   * layout   : fields stay dense row-major (last dim contiguous, :41-49).  A lane owns VK
+//                = 16 B of consecutive cells, a wave owns 64*VK cells of RJ consecutive rows,
+//                so every global access is a full 1 KiB coalesced wave transaction.
+//   * marching : a wave walks planes i = ib..ie of its (rows x columns) tile.  Plane i+R0+1
+//                is being fetched while plane i is computed; the 2*R0+1 live planes sit in
+//                VGPRs, so the i-neighbours cost no memory traffic at all.
+//   * J halo   : the RJ+2*R1 rows a wave needs are loaded by that wave; the 2*R1 extra rows
+//                are the neighbouring wave's own rows, i.e. L1/L2 hits when tiles that share
+//                rows run on the same XCD (see xcd_remap).
+//   * K halo   : the left/right neighbour cells come from the adjacent lane through a
+//                wave shift (DPP wave_shr/wave_shl, or ds_bpermute); the two cells just
+//                outside the wave's span have wave-uniform addresses and are fetched with
+//                scalar loads (s_load through the constant cache), costing SGPRs, not VGPRs.
+//   * fusion   : copy-through and the bounds test are folded into the store: cells outside
+//                apply.bounds get input 0's value, cells inside get body(...).  Nothing is
+//                written twice and no intermediate buffer exists.
+//   * no LDS, no barriers: waves are independent, latency is hidden by ~16 waves/CU each
+//                keeping a whole plane of loads in flight.
+//
+// Bandwidth accounting: algorithmic traffic is one read of every input cell + one write of
+// every result cell ((NIN+1)*N*sizeof(T)); redundant fetches are the J-halo rows (L2 hits)
+// and 2*R0 planes per chunk of `chunk` planes.
+#pragma once
+#include "apply_common.hpp"
+
+namespace neptune_hip {
+
+template <class T, int NIN>
+struct MarchParams {
+  const T* in[NIN];
+  T* out;
+  int32_t N0, N1, N2;      // extents along (I,J,K); identical for result and all inputs
+  int32_t plb[3], pub[3];  // apply.bounds in result-physical coordinates (lb - out_lb)
+  int64_t olb[3];          // result logical origin (only feeds the region's index arguments)
+  int32_t rI0, rI1;        // planes this launch is responsible for (result-physical)
+  int32_t chunk;           // planes per workgroup
+  uint32_t nJ, nK;         // tiles along J and K (tiles along I = gridDim.x / (nJ*nK))
+};
+
+template <class T> struct Vec16;
+template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// ---- wave shifts ----------------------------------------------------------------------
+// from_prev: lane l receives x of lane l-1, lane 0 receives `edge`.
+// from_next: lane l receives x of lane l+1, lane 63 receives `edge`.
+template <bool DPP>
+__device__ __forceinline__ int shift32_from_prev(int x, int edge, int lane) {
+  if constexpr (DPP) {
+    // v_mov_b32_dpp wave_shr:1 ; lane 0 has no source and keeps `old` (= edge)
+    return __builtin_amdgcn_update_dpp(edge, x, 0x138, 0xf, 0xf, false);
+  } else {
+    const int s = __shfl_up(x, 1);
+    return lane == 0 ? edge : s;
+  }
+}
+template <bool DPP>
+__device__ __forceinline__ int shift32_from_next(int x, int edge, int lane) {
+  if constexpr (DPP) {
+    // v_mov_b32_dpp wave_shl:1 ; lane 63 keeps `old`
+    return __builtin_amdgcn_update_dpp(edge, x, 0x130, 0xf, 0xf, false);
+  } else {
+    const int s = __shfl_down(x, 1);
+    return lane == kWave - 1 ? edge : s;
+  }
+}
+template <bool DPP>
+__device__ __forceinline__ float from_prev(float x, float edge, int lane) {
+  return __int_as_float(shift32_from_prev<DPP>(__float_as_int(x), __float_as_int(edge), lane));
+}
+template <bool DPP>
+__device__ __forceinline__ float from_next(float x, float edge, int lane) {
+  return __int_as_float(shift32_from_next<DPP>(__float_as_int(x), __float_as_int(edge), lane));
+}
+template <bool DPP>
+__device__ __forceinline__ double from_prev(double x, double edge, int lane) {
+  const int lo = shift32_from_prev<DPP>(__double2loint(x), __double2loint(edge), lane);
+  const int hi = shift32_from_prev<DPP>(__double2hiint(x), __double2hiint(edge), lane);
+  return __hiloint2double(hi, lo);
+}
+template <bool DPP>
+__device__ __forceinline__ double from_next(double x, double edge, int lane) {
+  const int lo = shift32_from_next<DPP>(__double2loint(x), __double2loint(edge), lane);
+  const int hi = shift32_from_next<DPP>(__double2hiint(x), __double2hiint(edge), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Wave-uniform read through the scalar data cache (s_load_*).  Only used on kernel inputs,
+// which no wave of this launch writes.
+template <class T>
+__device__ __forceinline__ T scalar_load(const T* p) {
+  typedef const __attribute__((address_space(4))) T* cptr;
+  return *(cptr)(p);
+}
+
+// ---- accessor handed to the body for the cell (row r, element e) of the wave tile -----
+template <class T, int RANK, int NIN, class FP, int RJ, int r, int e>
+struct MarchAcc {
+  static constexpr int VK = 16 / sizeof(T);
+  static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  static constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
+  // K neighbours exist for every live plane (box) or for the centre plane only (star)
+  static constexpr int NPH = FP::BOX ? NP : 1;
+  using V = typename Vec16<T>::type;
+
+  const V (&ring)[NP][NR];
+  const T (&lft)[NPH][NR][NS];
+  const T (&rgt)[NPH][NR][NS];
+  const V (&pt)[NIN][RJ];
+  int64_t li, lj, lk;  // logical coordinates along (I,J,K)
+
+  template <int IN, int... O>
+  __device__ __forceinline__ T get() const {
+    static_assert(IN >= 0 && IN < NIN, "input index out of range");
+    constexpr int oi = PickOffset<RANK, AxisMap<RANK>::I, O...>::value;
+    constexpr int oj = PickOffset<RANK, AxisMap<RANK>::J, O...>::value;
+    constexpr int ok = PickOffset<RANK, AxisMap<RANK>::K, O...>::value;
+    if constexpr (IN == HIN) {
+      static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2,
+                    "access outside the declared footprint");
+      static_assert(FP::BOX || ((oi != 0) + (oj != 0) + (ok != 0) <= 1),
+                    "star footprint declared but a diagonal access is used");
+      constexpr int p = oi + R0, s = r + R1 + oj, ke = e + ok;
+      constexpr int ph = FP::BOX ? p : 0;
+      if constexpr (ke < 0) return lft[ph][s][R2 + ke];
+      else if constexpr (ke >= VK) return rgt[ph][s][ke - VK];
+      else return ring[p][s][ke];
+    } else {
+      static_assert(oi == 0 && oj == 0 && ok == 0, "only the halo input may be read at an offset");
+      return pt[IN][r][e];
+    }
+  }
+  template <int D>
+  __device__ __forceinline__ int64_t idx() const {
+    static_assert(D >= 0 && D < RANK, "index argument out of range");
+    if constexpr (RANK == 3) return D == 0 ? li : (D == 1 ? lj : lk);
+    else if constexpr (RANK == 2) return D == 0 ? li : lk;
+    else return lk;
+  }
+};
+
+// ---- the kernel ---------------------------------------------------------------------------
+//   RJ    rows per lane            WJ x WK  waves per workgroup along J x K
+//   DPP   wave shifts by DPP (true) or ds_bpermute (false)
+//   NT    non-temporal stores for the result (it is never re-read by this launch)
+template <class Body, class T, int RANK, int NIN, class FP, int RJ, int WJ, int WK, bool DPP, bool NT>
+__global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams<T, NIN> P, Body body) {
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  constexpr bool BOX = FP::BOX;
+  constexpr bool HAS_HALO = HIN >= 0;
+  constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
+  // Scalar K halos: a box stencil needs them for every live plane, so they travel with the
+  // plane through the ring (fetched R0+1 steps ahead).  A star stencil needs them for the
+  // centre plane only, so they are fetched one step ahead and never ride the ring: 1/3 fewer
+  // live SGPRs for the 7-point stencil.
+  constexpr int NPH = BOX ? NP : 1;
+  constexpr int HLEAD = BOX ? R0 : 0;  // halos in flight belong to plane i+1+HLEAD
+  static_assert(R2 <= VK, "K radius larger than one lane's vector is not supported");
+  static_assert(HAS_HALO || (R0 == 0 && R1 == 0 && R2 == 0), "pointwise footprint must have zero radii");
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wj = w / WK, wk = w % WK;
+
+  // tile decode: K tiles fastest, then J tiles, then chunks of planes
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = v % P.nK;
+  const uint32_t t = v / P.nK;
+  const uint32_t jt = t % P.nJ;
+  const uint32_t ct = t / P.nJ;
+
+  // All in-plane index math is 32-bit (the host guarantees a plane is < 2 GiB); only the plane
+  // base is a 64-bit pointer.  Wave-uniform values live in SGPRs.
+  const int32_t j0 = (int32_t)(jt * (WJ * RJ)) + wj * RJ;              // first own row
+  const int32_t kw = (int32_t)((kt * WK + wk) * (uint32_t)(kWave * VK));  // first own column
+  if (j0 >= P.N1 || kw >= P.N2) return;                                 // wave-uniform
+  const int32_t k0 = kw + lane * VK;
+  const bool lane_ok = k0 < P.N2;  // N2 % VK == 0, so a lane is entirely in or out
+  const uint32_t lane_b = (uint32_t)(lane_ok ? k0 : P.N2 - VK) * (uint32_t)sizeof(T);
+  const int32_t kw_end = kw + kWave * VK;
+
+  const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
+  const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
+  if (ib >= ie) return;
+  const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
+
+  // byte offsets of the rows this wave touches (halo rows clamped into the field: a clamped
+  // row is only ever read for cells outside apply.bounds, whose body value is discarded)
+  uint32_t rowb[NR];
+  static_for<NR>([&](auto sc) {
+    constexpr int s = sc;
+    int32_t j = j0 + (s - R1);
+    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+    rowb[s] = (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  });
+  // byte offsets (within a row) of the cells just outside the wave's span, clamped
+  uint32_t khlb[NS], khrb[NS];
+  static_for<NS>([&](auto xc) {
+    constexpr int x = xc;
+    int32_t kl = kw - R2 + x;
+    kl = kl < 0 ? 0 : kl;
+    int32_t kr = kw_end + x;
+    kr = kr >= P.N2 ? P.N2 - 1 : kr;
+    khlb[x] = (uint32_t)kl * (uint32_t)sizeof(T);
+    khrb[x] = (uint32_t)kr * (uint32_t)sizeof(T);
+  });
+
+  // ---- register state ----
+  V ring[NP][NR];           // live planes of the halo input (row vectors)
+  T khl[NPH][NR][NS];       // scalar K halos, left  (wave-uniform)
+  T khr[NPH][NR][NS];       // scalar K halos, right
+  V nxt[NR];                // plane in flight
+  T nkhl[NR][NS], nkhr[NR][NS];
+  V pt[NIN][RJ];            // inputs read at offset 0 only, current plane
+  V npt[NIN][RJ];           // ... next plane, in flight
+
+  // rows whose K halo is needed: own rows always, J-halo rows only for box stencils
+  auto need_khalo = [](int s) constexpr { return R2 > 0 && (BOX || (s >= R1 && s < R1 + RJ)); };
+
+  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
+    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
+  };
+  auto load_rows = [&](int32_t ip, V(&rows)[NR]) {
+    if constexpr (HAS_HALO) {
+      const char* base = plane_base(P.in[HIN], ip);
+      static_for<NR>([&](auto sc) {
+        constexpr int s = sc;
+        rows[s] = *reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+      });
+    }
+  };
+  auto load_khalos = [&](int32_t ip, T(&hl)[NR][NS], T(&hr)[NR][NS]) {
+    if constexpr (HAS_HALO && R2 > 0) {
+      const char* base = plane_base(P.in[HIN], ip);
+      static_for<NR>([&](auto sc) {
+        constexpr int s = sc;
+        if constexpr (need_khalo(s)) {
+          static_for<R2>([&](auto xc) {
+            constexpr int x = xc;
+            hl[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[s] + khlb[x])));
+            hr[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[s] + khrb[x])));
+          });
+        }
+      });
+    }
+  };
+  auto load_point_inputs = [&](int32_t ip, V(&dst)[NIN][RJ]) {
+    static_for<NIN>([&](auto nc) {
+      constexpr int n = nc;
+      if constexpr (n != HIN) {
+        const char* base = plane_base(P.in[n], ip);
+        static_for<RJ>([&](auto rc) {
+          constexpr int r = rc;
+          dst[n][r] = *reinterpret_cast<const V*>(base + (rowb[r + R1] + lane_b));
+        });
+      }
+    });
+  };
+
+  // loop-invariant predicates
+  bool in_j[RJ], row_ok[RJ], in_k[VK];
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    in_j[r] = (j0 + r) >= P.plb[1] && (j0 + r) < P.pub[1];
+    row_ok[r] = (j0 + r) < P.N1;
+  });
+  static_for<VK>([&](auto ec) {
+    constexpr int e = ec;
+    in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
+  });
+
+  // ---- prologue: planes ib-R0 .. ib+R0-1 into ring[1..NP-1], plane ib+R0 in flight ----
+  static_for<NP - 1>([&](auto pc) {
+    constexpr int p = pc;
+    load_rows(ib - R0 + p, ring[p + 1]);  // shifted down at loop top
+    if constexpr (BOX) load_khalos(ib - R0 + p, khl[p + 1], khr[p + 1]);
+  });
+  load_rows(ib + R0, nxt);
+  load_khalos(ib + HLEAD, nkhl, nkhr);
+  load_point_inputs(ib, npt);
+
+  for (int32_t i = ib; i < ie; ++i) {
+    // rotate: ring[p] <- ring[p+1], newest plane <- nxt
+    static_for<NP - 1>([&](auto pc) {
+      constexpr int p = pc;
+      static_for<NR>([&](auto sc) {
+        constexpr int s = sc;
+        ring[p][s] = ring[p + 1][s];
+        if constexpr (BOX) {
+          static_for<NS>([&](auto xc) {
+            constexpr int x = xc;
+            khl[p][s][x] = khl[p + 1][s][x];
+            khr[p][s][x] = khr[p + 1][s][x];
+          });
+        }
+      });
+    });
+    static_for<NR>([&](auto sc) {
+      constexpr int s = sc;
+      ring[NP - 1][s] = nxt[s];
+      static_for<NS>([&](auto xc) {
+        constexpr int x = xc;
+        khl[NPH - 1][s][x] = nkhl[s][x];
+        khr[NPH - 1][s][x] = nkhr[s][x];
+      });
+    });
+    static_for<NIN>([&](auto nc) {
+      constexpr int n = nc;
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = npt[n][r]; });
+    });
+    // prefetch the next step's newest plane while this one is computed
+    if (i + 1 < ie) {
+      load_rows(i + 1 + R0, nxt);
+      load_khalos(i + 1 + HLEAD, nkhl, nkhr);
+      load_point_inputs(i + 1, npt);
+    }
+
+    // K neighbours from adjacent lanes (edges from the scalar halos)
+    T lft[NPH][NR][NS], rgt[NPH][NR][NS];
+    if constexpr (R2 > 0) {
+      static_for<NPH>([&](auto pc) {
+        constexpr int ph = pc;
+        constexpr int p = BOX ? ph : R0;  // star: centre plane only
+        static_for<NR>([&](auto sc) {
+          constexpr int s = sc;
+          // star stencils read K neighbours only on own rows
+          if constexpr (BOX || (s >= R1 && s < R1 + RJ)) {
+            static_for<R2>([&](auto xc) {
+              constexpr int x = xc;
+              lft[ph][s][x] = from_prev<DPP>(ring[p][s][VK - R2 + x], khl[ph][s][x], lane);
+              rgt[ph][s][x] = from_next<DPP>(ring[p][s][x], khr[ph][s][x], lane);
+            });
+          }
+        });
+      });
+    }
+
+    const bool in_i = i >= P.plb[0] && i < P.pub[0];
+    const int64_t li = (int64_t)i + P.olb[0];
+    char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      const int64_t lj = (int64_t)(j0 + r) + P.olb[1];
+      const bool in_ij = in_i && in_j[r];
+      V res;
+      static_for<VK>([&](auto ec) {
+        constexpr int e = ec;
+        const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
+        const bool inside = in_ij && in_k[e];
+        MarchAcc<T, RANK, NIN, FP, RJ, r, e> acc{ring, lft, rgt, pt, li, lj, lk};
+        const T val = body(acc);
+        T through;  // copy-through source: input 0 at the same physical index
+        if constexpr (HIN == 0) through = ring[R0][r + R1][e];
+        else through = pt[0][r][e];
+        res[e] = inside ? val : through;
+      });
+      if (row_ok[r] && lane_ok) {
+        // rowb[r+R1] is this own row's offset (own rows are never clamped when row_ok)
+        V* dst = reinterpret_cast<V*>(obase + (rowb[r + R1] + lane_b));
+        if constexpr (NT) __builtin_nontemporal_store(res, dst);
+        else *dst = res;
+      }
+    });
+  }
+}
+
+}  // namespace neptune_hip

@@ -1,0 +1,64 @@
+// util_kernels.hpp -- store (box copy), streaming copy, deterministic fill and bitwise
+// compare kernels around the apply kernels.
+#pragma once
+#include "apply_common.hpp"
+
+namespace neptune_hip {
+
+// neptune_ir.store with bounds (lib/Passes/DataflowLowering.cpp:184-217): the logical box
+// [lb,ub) is copied between two buffers that each have their own logical origin.
+// Per-axis arrays in (I,J,K) order; absent axes extent 1.
+struct BoxCopyParams {
+  int64_t ext[3];     // ub - lb
+  int64_t soff[3];    // lb - src_lb
+  int64_t doff[3];    // lb - dst_lb
+  int64_t sshape[3];  // src buffer extents
+  int64_t dshape[3];  // dst buffer extents
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void neptune_store_box(const T* __restrict__ src, T* __restrict__ dst,
+                                                         BoxCopyParams P) {
+  const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
+  const int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (flat >= total) return;
+  const int64_t row = flat / P.ext[2];
+  const int64_t k = flat - row * P.ext[2];
+  const int64_t j = row % P.ext[1];
+  const int64_t i = row / P.ext[1];
+  const int64_t s = ((i + P.soff[0]) * P.sshape[1] + (j + P.soff[1])) * P.sshape[2] + (k + P.soff[2]);
+  const int64_t d = ((i + P.doff[0]) * P.dshape[1] + (j + P.doff[1])) * P.dshape[2] + (k + P.doff[2]);
+  dst[d] = src[s];
+}
+
+// 16 B per lane streaming copy: the measured HBM ceiling the apply kernels are compared with.
+// Grid-stride; n16 = number of 16-byte words.
+__global__ __launch_bounds__(256) void neptune_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                      int64_t n16) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void neptune_fill_hash(T* __restrict__ dst, int64_t count, int64_t index_offset,
+                                                         uint64_t seed) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+    if constexpr (sizeof(T) == 8) dst[i] = hash_f64(i + index_offset, seed);
+    else dst[i] = hash_f32(i + index_offset, seed);
+  }
+}
+
+// counts elements whose bit patterns differ (NaN-safe, -0.0 != +0.0)
+template <class U>
+__global__ __launch_bounds__(256) void neptune_count_mismatch(const U* __restrict__ a, const U* __restrict__ b,
+                                                              int64_t count, unsigned long long* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  unsigned long long local = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) local += (a[i] != b[i]);
+  // wave reduction, then one atomic per wave
+  for (int off = kWave / 2; off > 0; off >>= 1) local += __shfl_down(local, off);
+  if ((threadIdx.x & (kWave - 1)) == 0 && local) atomicAdd(out, local);
+}
+
+}  // namespace neptune_hip

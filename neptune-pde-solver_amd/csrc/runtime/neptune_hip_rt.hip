@@ -1,0 +1,408 @@
+// neptune_hip_rt.hip -- implementation of include/neptune_hip.h: the thin C-ABI runtime the
+// emitted host code, the Python frontend and the bench call into.  gfx950 only.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+//   -ffp-contract=off is part of the contract: the reference evaluates body ops one by one in
+//   strict IEEE with no FMA (lib/Pipeline/NeptuneIRPassesPipeline.cpp:28-46 has no fusing
+//   pass; lib/Compiler/NeptuneCompiler.cpp:332-337 targets cpu "generic"), and parity with
+//   it is bit-exact only if the device code does the same.
+#define NEPTUNE_HIP_FULL_VARIANTS 1
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "../../../include/neptune_hip.h"
+#include "../kernels/apply_launch.hpp"
+#include "../kernels/util_kernels.hpp"
+#include "builtin_bodies.hpp"
+
+using namespace neptune_hip;
+
+namespace {
+
+struct RuntimeState {
+  std::mutex mu;
+  bool inited = false;
+  int device = -1;
+  char arch[256] = "unknown";
+  int cus = 0;
+  unsigned long long* counter = nullptr;  // device word for count_mismatch
+};
+RuntimeState& rt() {
+  static RuntimeState s;
+  return s;
+}
+
+[[noreturn]] void die(const char* what) {
+  fprintf(stderr, "[NeptuneRT][HIP] %s\n", what);
+  abort();
+}
+
+void ensure_init() {
+  RuntimeState& s = rt();
+  if (s.inited) return;
+  neptune_hip_init(s.device < 0 ? 0 : s.device);
+}
+
+inline hipStream_t as_stream(void* p) { return reinterpret_cast<hipStream_t>(p); }
+
+template <class B>
+int apply_body(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, hipStream_t stream,
+               const neptune_hip_launch_cfg_t* cfg) {
+  int rc = geom_check_radius(g, B::radius);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  return launch_apply<B, typename B::T, B::RANK, B::NIN, typename B::FP>(B{}, g, in, out, stream, cfg);
+}
+template <class B>
+int plan_body(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out,
+              const neptune_hip_launch_cfg_t* cfg) {
+  int rc = geom_check_radius(g, B::radius);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  return plan_apply<typename B::T, B::RANK, B::NIN, typename B::FP>(g, in, out, cfg);
+}
+
+// out must not overlap an input: every wave reads neighbours other waves may already have
+// overwritten.  (The reference materialises a fresh buffer per apply, DataflowLowering.cpp:281.)
+bool overlaps(const void* a, size_t na, const void* b, size_t nb) {
+  const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+  return x < y + nb && y < x + na;
+}
+size_t geom_bytes(const int64_t* lb, const int64_t* ub, int rank, size_t elem) {
+  size_t n = elem;
+  for (int d = 0; d < rank; ++d) n *= (size_t)(ub[d] - lb[d]);
+  return n;
+}
+int check_no_alias(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out, size_t elem) {
+  const size_t ob = geom_bytes(g->out_lb, g->out_ub, g->rank, elem);
+  for (int k = 0; k < g->num_inputs; ++k) {
+    const size_t ib = geom_bytes(g->in_lb[k], g->in_ub[k], g->rank, elem);
+    if (overlaps(in[k], ib, out, ob)) return NEPTUNE_HIP_EINVAL;
+  }
+  return NEPTUNE_HIP_OK;
+}
+
+size_t body_elem_size(int body) { return body == NEPTUNE_HIP_BODY_LAP3D27_F32 ? 4 : 8; }
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------- runtime
+void neptune_hip_init(int device) {
+  RuntimeState& s = rt();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (s.inited && s.device == device) return;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) die("no HIP device available");
+  if (device < 0 || device >= count) die("neptune_hip_init: device index out of range");
+  NEPTUNE_HIP_CHECK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  NEPTUNE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  strncpy(s.arch, prop.gcnArchName, sizeof(s.arch) - 1);
+  s.cus = prop.multiProcessorCount;
+  if (strncmp(s.arch, "gfx950", 6) != 0)
+    fprintf(stderr, "[NeptuneRT][HIP] warning: built for gfx950, device reports %s\n", s.arch);
+  if (!s.counter) NEPTUNE_HIP_CHECK(hipMalloc((void**)&s.counter, sizeof(unsigned long long)));
+  s.device = device;
+  s.inited = true;
+}
+
+void neptune_hip_finalize(void) {
+  RuntimeState& s = rt();
+  std::lock_guard<std::mutex> lk(s.mu);
+  if (!s.inited) return;
+  if (s.counter) {
+    (void)hipFree(s.counter);
+    s.counter = nullptr;
+  }
+  s.inited = false;
+}
+
+int neptune_hip_available(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+  return count > 0 ? 1 : 0;
+}
+
+const char* neptune_hip_arch(void) {
+  ensure_init();
+  return rt().arch;
+}
+int neptune_hip_cu_count(void) {
+  ensure_init();
+  return rt().cus;
+}
+const char* neptune_hip_version(void) { return "neptune-hip 0.1 (gfx950, ffp-contract=off)"; }
+
+void* neptune_hip_malloc(size_t bytes) {
+  ensure_init();
+  void* p = nullptr;
+  if (bytes == 0) bytes = 16;
+  NEPTUNE_HIP_CHECK(hipMalloc(&p, bytes));
+  return p;
+}
+void neptune_hip_free(void* dptr) {
+  if (dptr) NEPTUNE_HIP_CHECK(hipFree(dptr));
+}
+void neptune_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  NEPTUNE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+}
+void neptune_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  NEPTUNE_HIP_CHECK(hipStreamSynchronize(as_stream(stream)));
+}
+void neptune_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+}
+void neptune_hip_stream_sync(void* stream) { NEPTUNE_HIP_CHECK(hipStreamSynchronize(as_stream(stream))); }
+void neptune_hip_device_sync(void) { NEPTUNE_HIP_CHECK(hipDeviceSynchronize()); }
+
+int neptune_hip_is_device_ptr(const void* p) {
+  if (!p) return 0;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory is reported as an error; clear it
+    return 0;
+  }
+  return attr.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+void neptune_rt_free(void* p) {
+  if (!p) return;
+  if (neptune_hip_is_device_ptr(p)) NEPTUNE_HIP_CHECK(hipFree(p));
+  else free(p);
+}
+
+// ---------------------------------------------------------------- apply
+int neptune_hip_check_geom(const neptune_hip_apply_geom_t* g,
+                           const int32_t radius[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK]) {
+  if (!radius) return geom_validate(g);
+  return geom_check_radius(g, radius);
+}
+
+int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                              void* stream, const neptune_hip_launch_cfg_t* cfg) {
+  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
+  if (body < 0 || body >= NEPTUNE_HIP_BODY_COUNT) return NEPTUNE_HIP_EINVAL;
+  int rc = geom_validate(g);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  for (int k = 0; k < g->num_inputs; ++k)
+    if (!in[k]) return NEPTUNE_HIP_EINVAL;
+  rc = check_no_alias(g, in, out, body_elem_size(body));
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  ensure_init();
+  hipStream_t s = as_stream(stream);
+  switch (body) {
+    case NEPTUNE_HIP_BODY_LAP2D5_F64: return apply_body<builtin::Lap2D5>(g, in, out, s, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D7_F64: return apply_body<builtin::Lap3D7>(g, in, out, s, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D27_F32: return apply_body<builtin::Lap3D27>(g, in, out, s, cfg);
+    case NEPTUNE_HIP_BODY_LAP1D3_F64: return apply_body<builtin::Lap1D3>(g, in, out, s, cfg);
+  }
+  return NEPTUNE_HIP_EINVAL;
+}
+
+int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t* g, const void* const* in,
+                                   const void* out, const neptune_hip_launch_cfg_t* cfg) {
+  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
+  switch (body) {
+    case NEPTUNE_HIP_BODY_LAP2D5_F64: return plan_body<builtin::Lap2D5>(g, in, out, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D7_F64: return plan_body<builtin::Lap3D7>(g, in, out, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D27_F32: return plan_body<builtin::Lap3D27>(g, in, out, cfg);
+    case NEPTUNE_HIP_BODY_LAP1D3_F64: return plan_body<builtin::Lap1D3>(g, in, out, cfg);
+  }
+  return NEPTUNE_HIP_EINVAL;
+}
+
+const char* neptune_hip_kernel_name(int kernel) {
+  switch (kernel) {
+    case NEPTUNE_HIP_KERNEL_DIRECT: return "neptune_apply_direct";
+    case NEPTUNE_HIP_KERNEL_MARCH: return "neptune_apply_march";
+  }
+  return "";
+}
+int neptune_hip_march_variant_count(int rank) { return march_variant_count(rank); }
+const char* neptune_hip_march_variant_name(int rank, int variant) {
+  const MarchVariant* v = march_variant(rank, variant);
+  return v ? v->name : "";
+}
+
+// ---------------------------------------------------------------- store
+int neptune_hip_store_full(int dtype, const void* src, void* dst, int64_t count, void* stream) {
+  if (!src || !dst || count < 0) return NEPTUNE_HIP_EINVAL;
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
+  const size_t bytes = (size_t)count * (dtype == NEPTUNE_HIP_F64 ? 8 : 4);
+  if (bytes == 0 || src == dst) return NEPTUNE_HIP_OK;
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return NEPTUNE_HIP_OK;
+}
+
+int neptune_hip_store_box(int dtype, int rank, const void* src, const int64_t* src_lb, const int64_t* src_ub,
+                          void* dst, const int64_t* dst_lb, const int64_t* dst_ub, const int64_t* lb,
+                          const int64_t* ub, void* stream) {
+  if (!src || !dst || !src_lb || !src_ub || !dst_lb || !dst_ub || !lb || !ub) return NEPTUNE_HIP_EINVAL;
+  if (rank < 1 || rank > kMaxRank) return NEPTUNE_HIP_EINVAL;
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
+  int64_t ext[3], soff[3], doff[3], ss[3], ds[3];
+  for (int d = 0; d < rank; ++d) {
+    ext[d] = ub[d] - lb[d];
+    soff[d] = lb[d] - src_lb[d];
+    doff[d] = lb[d] - dst_lb[d];
+    ss[d] = src_ub[d] - src_lb[d];
+    ds[d] = dst_ub[d] - dst_lb[d];
+    if (ext[d] < 0 || ss[d] <= 0 || ds[d] <= 0) return NEPTUNE_HIP_EINVAL;
+    // the subviews of the reference (DataflowLowering.cpp:212-215) must lie inside their buffers
+    if (ext[d] > 0 && (soff[d] < 0 || soff[d] + ext[d] > ss[d] || doff[d] < 0 || doff[d] + ext[d] > ds[d]))
+      return NEPTUNE_HIP_EOOB;
+  }
+  BoxCopyParams P;
+  auto fill = [&](const int64_t* a, int64_t* o, int64_t f) {
+    o[0] = o[1] = o[2] = f;
+    if (rank == 3) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+    else if (rank == 2) { o[0] = a[0]; o[2] = a[1]; }
+    else { o[2] = a[0]; }
+  };
+  fill(ext, P.ext, 1);
+  fill(soff, P.soff, 0);
+  fill(doff, P.doff, 0);
+  fill(ss, P.sshape, 1);
+  fill(ds, P.dshape, 1);
+  const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
+  if (total == 0) return NEPTUNE_HIP_OK;
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
+  ensure_init();
+  if (dtype == NEPTUNE_HIP_F64)
+    hipLaunchKernelGGL(neptune_store_box<double>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+                       (const double*)src, (double*)dst, P);
+  else
+    hipLaunchKernelGGL(neptune_store_box<float>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+                       (const float*)src, (float*)dst, P);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
+// ---------------------------------------------------------------- helpers
+int neptune_hip_fill_hash(int dtype, void* dst, int64_t count, int64_t index_offset, uint64_t seed,
+                          void* stream) {
+  if (!dst || count < 0) return NEPTUNE_HIP_EINVAL;
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
+  if (count == 0) return NEPTUNE_HIP_OK;
+  ensure_init();
+  const int64_t want = (count + 255) / 256;
+  const uint32_t blocks = (uint32_t)(want < 8192 ? want : 8192);
+  if (dtype == NEPTUNE_HIP_F64)
+    hipLaunchKernelGGL(neptune_fill_hash<double>, dim3(blocks), dim3(256), 0, as_stream(stream), (double*)dst,
+                       count, index_offset, seed);
+  else
+    hipLaunchKernelGGL(neptune_fill_hash<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (float*)dst,
+                       count, index_offset, seed);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
+double neptune_hip_hash_value(int dtype, int64_t index, uint64_t seed) {
+  return dtype == NEPTUNE_HIP_F32 ? (double)hash_f32(index, seed) : hash_f64(index, seed);
+}
+
+int64_t neptune_hip_count_mismatch(int dtype, const void* a, const void* b, int64_t count, void* stream) {
+  if (!a || !b || count < 0) return -1;
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return -1;
+  if (count == 0) return 0;
+  ensure_init();
+  RuntimeState& s = rt();
+  hipStream_t st = as_stream(stream);
+  NEPTUNE_HIP_CHECK(hipMemsetAsync(s.counter, 0, sizeof(unsigned long long), st));
+  const int64_t want = (count + 255) / 256;
+  const uint32_t blocks = (uint32_t)(want < 8192 ? want : 8192);
+  if (dtype == NEPTUNE_HIP_F64)
+    hipLaunchKernelGGL(neptune_count_mismatch<unsigned long long>, dim3(blocks), dim3(256), 0, st,
+                       (const unsigned long long*)a, (const unsigned long long*)b, count, s.counter);
+  else
+    hipLaunchKernelGGL(neptune_count_mismatch<unsigned int>, dim3(blocks), dim3(256), 0, st,
+                       (const unsigned int*)a, (const unsigned int*)b, count, s.counter);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  unsigned long long host = 0;
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(&host, s.counter, sizeof(host), hipMemcpyDeviceToHost, st));
+  NEPTUNE_HIP_CHECK(hipStreamSynchronize(st));
+  return (int64_t)host;
+}
+
+double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in,
+                                      void* out, void* stream, const neptune_hip_launch_cfg_t* cfg, int warmup,
+                                      int reps) {
+  if (reps <= 0) return -1.0;
+  hipStream_t st = as_stream(stream);
+  for (int i = 0; i < warmup; ++i) {
+    int rc = neptune_hip_apply_builtin(body, g, in, out, stream, cfg);
+    if (rc != NEPTUNE_HIP_OK) return (double)rc;
+  }
+  hipEvent_t e0, e1;
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+  NEPTUNE_HIP_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) {
+    int rc = neptune_hip_apply_builtin(body, g, in, out, stream, cfg);
+    if (rc != NEPTUNE_HIP_OK) return (double)rc;
+  }
+  NEPTUNE_HIP_CHECK(hipEventRecord(e1, st));
+  NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e0));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e1));
+  return (double)ms / reps;
+}
+
+double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* stream, int warmup, int reps) {
+  if (!dst || !src || reps <= 0 || bytes % 16 != 0) return -1.0;
+  ensure_init();
+  hipStream_t st = as_stream(stream);
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const uint32_t blocks = 256 * 8;  // 8 workgroups of 256 lanes per CU, grid-stride
+  auto launch = [&] {
+    hipLaunchKernelGGL(neptune_copy16, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);
+  };
+  for (int i = 0; i < warmup; ++i) launch();
+  hipEvent_t e0, e1;
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+  NEPTUNE_HIP_CHECK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) launch();
+  NEPTUNE_HIP_CHECK(hipEventRecord(e1, st));
+  NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  float ms = 0.f;
+  NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e0));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e1));
+  return (double)ms / reps;
+}
+
+void* neptune_hip_event_create(void) {
+  ensure_init();
+  hipEvent_t e;
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e));
+  return (void*)e;
+}
+void neptune_hip_event_destroy(void* ev) {
+  if (ev) NEPTUNE_HIP_CHECK(hipEventDestroy((hipEvent_t)ev));
+}
+void neptune_hip_event_record(void* ev, void* stream) {
+  NEPTUNE_HIP_CHECK(hipEventRecord((hipEvent_t)ev, as_stream(stream)));
+}
+void neptune_hip_event_sync(void* ev) { NEPTUNE_HIP_CHECK(hipEventSynchronize((hipEvent_t)ev)); }
+double neptune_hip_event_elapsed_ms(void* start, void* stop) {
+  float ms = 0.f;
+  NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return (double)ms;
+}
+void neptune_hip_stream_wait_event(void* stream, void* ev) {
+  NEPTUNE_HIP_CHECK(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)ev, 0));
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+"""ctypes binding of include/neptune_hip.h (the C-ABI drop-in boundary).
+
+Nothing here computes anything: it declares the signatures of libneptune_hip.so and loads it.
+There is deliberately no CPU fallback -- if the HIP library is missing the import of the
+product path fails loudly (tests/test_capi.py checks that every symbol the header declares is
+exported and bound here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+PKG_ROOT = Path(__file__).resolve().parent.parent          # neptune-pde-solver_amd/
+REPO_ROOT = PKG_ROOT.parent
+LIB_PATH = PKG_ROOT / "lib" / "libneptune_hip.so"
+HEADER_PATH = REPO_ROOT / "include" / "neptune_hip.h"
+
+MAX_RANK = 3
+MAX_INPUTS = 4
+
+OK, EINVAL, EUNSUPPORTED, EOOB = 0, -1, -2, -3
+F64, F32 = 0, 1
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MARCH = 0, 1, 2
+BODY_LAP2D5_F64, BODY_LAP3D7_F64, BODY_LAP3D27_F32, BODY_LAP1D3_F64 = 0, 1, 2, 3
+
+ERROR_NAMES = {EINVAL: "NEPTUNE_HIP_EINVAL", EUNSUPPORTED: "NEPTUNE_HIP_EUNSUPPORTED", EOOB: "NEPTUNE_HIP_EOOB"}
+
+
+class NeptuneHipError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{what}: {ERROR_NAMES.get(code, code)}")
+        self.code = code
+
+
+class ApplyGeom(C.Structure):
+    """neptune_hip_apply_geom_t"""
+    _fields_ = [
+        ("rank", C.c_int32),
+        ("num_inputs", C.c_int32),
+        ("out_lb", C.c_int64 * MAX_RANK),
+        ("out_ub", C.c_int64 * MAX_RANK),
+        ("lb", C.c_int64 * MAX_RANK),
+        ("ub", C.c_int64 * MAX_RANK),
+        ("in_lb", (C.c_int64 * MAX_RANK) * MAX_INPUTS),
+        ("in_ub", (C.c_int64 * MAX_RANK) * MAX_INPUTS),
+        ("region_lb", C.c_int64 * MAX_RANK),
+        ("region_ub", C.c_int64 * MAX_RANK),
+    ]
+
+
+class LaunchCfg(C.Structure):
+    """neptune_hip_launch_cfg_t"""
+    _fields_ = [("kernel", C.c_int32), ("variant", C.c_int32), ("chunk", C.c_int32), ("flags", C.c_int32)]
+
+
+def _memref(rank: int):
+    class _M(C.Structure):
+        _fields_ = [("allocated", C.c_void_p), ("aligned", C.c_void_p), ("offset", C.c_int64),
+                    ("sizes", C.c_int64 * rank), ("strides", C.c_int64 * rank)]
+    _M.__name__ = f"NeptuneMemRef{rank}D"
+    return _M
+
+
+NeptuneMemRef1D, NeptuneMemRef2D, NeptuneMemRef3D = _memref(1), _memref(2), _memref(3)
+MEMREF = {1: NeptuneMemRef1D, 2: NeptuneMemRef2D, 3: NeptuneMemRef3D}
+
+_vp, _i, _i64, _u64, _sz, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t, C.c_double
+_geom_p, _cfg_p = C.POINTER(ApplyGeom), C.POINTER(LaunchCfg)
+_vpp = C.POINTER(C.c_void_p)
+_i64p = C.POINTER(C.c_int64)
+_radius_p = C.POINTER((C.c_int32 * MAX_RANK) * MAX_INPUTS)
+
+# name -> (restype, argtypes); must list every function include/neptune_hip.h declares
+SIGNATURES = {
+    "neptune_hip_init": (None, [_i]),
+    "neptune_hip_finalize": (None, []),
+    "neptune_hip_available": (_i, []),
+    "neptune_hip_arch": (C.c_char_p, []),
+    "neptune_hip_cu_count": (_i, []),
+    "neptune_hip_version": (C.c_char_p, []),
+    "neptune_hip_malloc": (_vp, [_sz]),
+    "neptune_hip_free": (None, [_vp]),
+    "neptune_hip_memcpy_h2d": (None, [_vp, _vp, _sz, _vp]),
+    "neptune_hip_memcpy_d2h": (None, [_vp, _vp, _sz, _vp]),
+    "neptune_hip_memcpy_d2d": (None, [_vp, _vp, _sz, _vp]),
+    "neptune_hip_stream_sync": (None, [_vp]),
+    "neptune_hip_device_sync": (None, []),
+    "neptune_hip_is_device_ptr": (_i, [_vp]),
+    "neptune_rt_free": (None, [_vp]),
+    "neptune_hip_check_geom": (_i, [_geom_p, _radius_p]),
+    "neptune_hip_apply_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p]),
+    "neptune_hip_apply_builtin_plan": (_i, [_i, _geom_p, _vpp, _vp, _cfg_p]),
+    "neptune_hip_kernel_name": (C.c_char_p, [_i]),
+    "neptune_hip_march_variant_count": (_i, [_i]),
+    "neptune_hip_march_variant_name": (C.c_char_p, [_i, _i]),
+    "neptune_hip_store_full": (_i, [_i, _vp, _vp, _i64, _vp]),
+    "neptune_hip_store_box": (_i, [_i, _i, _vp, _i64p, _i64p, _vp, _i64p, _i64p, _i64p, _i64p, _vp]),
+    "neptune_hip_fill_hash": (_i, [_i, _vp, _i64, _i64, _u64, _vp]),
+    "neptune_hip_hash_value": (_dbl, [_i, _i64, _u64]),
+    "neptune_hip_count_mismatch": (_i64, [_i, _vp, _vp, _i64, _vp]),
+    "neptune_hip_time_apply_builtin": (_dbl, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p, _i, _i]),
+    "neptune_hip_time_copy": (_dbl, [_vp, _vp, _sz, _vp, _i, _i]),
+    "neptune_hip_event_create": (_vp, []),
+    "neptune_hip_event_destroy": (None, [_vp]),
+    "neptune_hip_event_record": (None, [_vp, _vp]),
+    "neptune_hip_event_sync": (None, [_vp]),
+    "neptune_hip_event_elapsed_ms": (_dbl, [_vp, _vp]),
+    "neptune_hip_stream_wait_event": (None, [_vp, _vp]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libneptune_hip.so (built by `make rt` / __graft_entry__.build()).  No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = Path(os.environ.get("NEPTUNE_HIP_LIB", LIB_PATH))
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found: the NeptuneIR HIP backend has no CPU fallback. "
+            "Build it with `make rt` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)  # RTLD_GLOBAL: lowered modules resolve neptune_hip_* against it
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> int:
+    if code < 0:
+        raise NeptuneHipError(code, what)
+    return code

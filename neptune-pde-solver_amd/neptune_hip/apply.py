@@ -1,0 +1,101 @@
+"""Host-side launch of the apply hot path through the C ABI (neptune_hip_apply_builtin & co).
+
+This is the thin layer the Python frontend, the tests and the bench share; it mirrors what the
+emitted host C++ of a lowered module does for one `neptune_ir.apply` + `neptune_ir.store`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+from . import _capi
+from .fields import DeviceField, current_stream_ptr
+from .geometry import Box, make_geom
+
+BODY_BY_NAME = {
+    "lap2d5_f64": _capi.BODY_LAP2D5_F64,
+    "lap3d7_f64": _capi.BODY_LAP3D7_F64,
+    "lap3d27_f32": _capi.BODY_LAP3D27_F32,
+    "lap1d3_f64": _capi.BODY_LAP1D3_F64,
+}
+BODY_DTYPE = {_capi.BODY_LAP2D5_F64: _capi.F64, _capi.BODY_LAP3D7_F64: _capi.F64,
+              _capi.BODY_LAP3D27_F32: _capi.F32, _capi.BODY_LAP1D3_F64: _capi.F64}
+BODY_RANK = {_capi.BODY_LAP2D5_F64: 2, _capi.BODY_LAP3D7_F64: 3, _capi.BODY_LAP3D27_F32: 3,
+             _capi.BODY_LAP1D3_F64: 1}
+BODY_POINTS = {_capi.BODY_LAP2D5_F64: 5, _capi.BODY_LAP3D7_F64: 7, _capi.BODY_LAP3D27_F32: 27,
+               _capi.BODY_LAP1D3_F64: 3}
+
+
+def _in_array(inputs: Sequence[DeviceField]):
+    arr = (C.c_void_p * len(inputs))(*[f.ptr for f in inputs])
+    return arr
+
+
+def make_cfg(kernel: int = _capi.KERNEL_AUTO, variant: int = 0, chunk: int = 0) -> _capi.LaunchCfg:
+    return _capi.LaunchCfg(kernel, variant, chunk, 0)
+
+
+def geom_for(inputs: Sequence[DeviceField], out: DeviceField, bounds: Box, region: Optional[Box] = None):
+    return make_geom(out.box, bounds, [f.box for f in inputs], region)
+
+
+def apply_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+                  region: Optional[Box] = None, cfg: Optional[_capi.LaunchCfg] = None,
+                  stream: Optional[int] = None) -> None:
+    """out = apply(inputs) {bounds} with the built-in body; asynchronous on `stream`."""
+    lib = _capi.load()
+    g = geom_for(inputs, out, bounds, region)
+    rc = lib.neptune_hip_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
+                                       current_stream_ptr() if stream is None else stream,
+                                       C.byref(cfg) if cfg is not None else None)
+    _capi.check(rc, "neptune_hip_apply_builtin")
+
+
+def plan_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+                 region: Optional[Box] = None, cfg: Optional[_capi.LaunchCfg] = None) -> int:
+    lib = _capi.load()
+    g = geom_for(inputs, out, bounds, region)
+    return _capi.check(lib.neptune_hip_apply_builtin_plan(body, C.byref(g), _in_array(inputs), out.ptr,
+                                                          C.byref(cfg) if cfg is not None else None),
+                       "neptune_hip_apply_builtin_plan")
+
+
+def time_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+                 cfg: Optional[_capi.LaunchCfg] = None, warmup: int = 3, reps: int = 20,
+                 stream: Optional[int] = None) -> float:
+    """average milliseconds per launch, HIP events on the launch stream (blocking)"""
+    lib = _capi.load()
+    g = geom_for(inputs, out, bounds)
+    ms = lib.neptune_hip_time_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
+                                            current_stream_ptr() if stream is None else stream,
+                                            C.byref(cfg) if cfg is not None else None, warmup, reps)
+    if ms < 0:
+        raise _capi.NeptuneHipError(int(ms), "neptune_hip_time_apply_builtin")
+    return ms
+
+
+def store(src: DeviceField, dst: DeviceField, bounds: Optional[Box] = None, stream: Optional[int] = None) -> None:
+    """neptune_ir.store %src to %dst {bounds?}  (DataflowLowering.cpp:165-220)"""
+    lib = _capi.load()
+    st = current_stream_ptr() if stream is None else stream
+    if src.dtype != dst.dtype:
+        raise ValueError("store: element types differ")
+    if bounds is None:
+        if src.shape != dst.shape:
+            raise ValueError("store: shapes differ")
+        _capi.check(lib.neptune_hip_store_full(src.dtype, src.ptr, dst.ptr, src.count, st), "neptune_hip_store_full")
+        return
+    r = src.rank
+    arr = lambda v: (C.c_int64 * r)(*[int(x) for x in v])
+    _capi.check(lib.neptune_hip_store_box(src.dtype, r, src.ptr, arr(src.lb), arr(src.ub), dst.ptr, arr(dst.lb),
+                                          arr(dst.ub), arr(bounds[0]), arr(bounds[1]), st), "neptune_hip_store_box")
+
+
+def count_mismatch(a: DeviceField, b: DeviceField) -> int:
+    lib = _capi.load()
+    if a.dtype != b.dtype or a.shape != b.shape:
+        raise ValueError("count_mismatch: fields differ in type or shape")
+    n = lib.neptune_hip_count_mismatch(a.dtype, a.ptr, b.ptr, a.count, current_stream_ptr())
+    if n < 0:
+        raise RuntimeError("neptune_hip_count_mismatch failed")
+    return int(n)

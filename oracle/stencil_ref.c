@@ -1,0 +1,241 @@
+/*
+ * stencil_ref.c -- C restatement of what the reference's `neptuneir-to-llvm` pipeline executes
+ * for the committed stencil fixtures.  TEST INFRASTRUCTURE (parity checker and the bench's
+ * cpu_baseline leg); the product never links or loads it.
+ *
+ * PARITY UNPINNED: the reference holds no expected outputs for this path and cannot be built
+ * in this image (needs MLIR/LLVM 21.x); see oracle/neptune_oracle.py's header.  This file is
+ * cross-checked bit-for-bit against that numpy restatement (tests/test_oracle.py) and against
+ * the hand-derived known-answer vectors in tests/golden/.
+ *
+ * "faithful" entry points reproduce the lowered @entry of each fixture step by step
+ * (reference: lib/Passes/DataflowLowering.cpp):
+ *     tmp = malloc(N)                       memref.alloc            :281
+ *     memcpy(tmp, in)                       copy-through of input 0 :283-287
+ *     for p in apply.bounds (row-major)     scf.for nest            :289-308
+ *         tmp[p - out_lb] = body(in[p+off - in_lb])   access/yield  :380-444
+ *     memcpy(out, tmp)                      neptune_ir.store        :176-179
+ *     free(tmp)                             (caller frees the apply result)
+ * one thread, scalar, no FMA (build: -O2 -fno-tree-vectorize -ffp-contract=off), body ops in the
+ * fixture's textual order.
+ *
+ * "fused" entry points are the honest CPU ceiling quoted beside it: one pass, copy-through
+ * folded in, OpenMP over dim 0 -- same bits, different schedule.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define IDX2(i, j, n1) ((size_t)(i) * (size_t)(n1) + (size_t)(j))
+#define IDX3(i, j, k, n1, n2) (((size_t)(i) * (size_t)(n1) + (size_t)(j)) * (size_t)(n2) + (size_t)(k))
+
+/* ---- bodies: one statement per IR op, textual order ------------------------------------ */
+/* tests/mlir_tests/conversion_tests/apply-2d-5pt.mlir */
+static inline double body_lap2d5(const double *u, int64_t i, int64_t j, int64_t n1) {
+  const double c = u[IDX2(i, j, n1)];
+  const double n = u[IDX2(i - 1, j, n1)];
+  const double s = u[IDX2(i + 1, j, n1)];
+  const double w = u[IDX2(i, j - 1, n1)];
+  const double e = u[IDX2(i, j + 1, n1)];
+  const double four = 4.0;
+  const double dxinv2 = 0.125;
+  const double t0 = n + s;
+  const double t1 = t0 + w;
+  const double t2 = t1 + e;
+  const double t3 = four * c;
+  const double t4 = t2 - t3;
+  const double lap = dxinv2 * t4;
+  return lap;
+}
+
+/* tests/mlir_tests/conversion_tests/apply-3d-7pt.mlir */
+static inline double body_lap3d7(const double *u, int64_t i, int64_t j, int64_t k, int64_t n1, int64_t n2) {
+  const double c = u[IDX3(i, j, k, n1, n2)];
+  const double xm = u[IDX3(i - 1, j, k, n1, n2)];
+  const double xp = u[IDX3(i + 1, j, k, n1, n2)];
+  const double ym = u[IDX3(i, j - 1, k, n1, n2)];
+  const double yp = u[IDX3(i, j + 1, k, n1, n2)];
+  const double zm = u[IDX3(i, j, k - 1, n1, n2)];
+  const double zp = u[IDX3(i, j, k + 1, n1, n2)];
+  const double six = 6.0;
+  const double dxinv2 = 0.0625;
+  const double t0 = xm + xp;
+  const double t1 = t0 + ym;
+  const double t2 = t1 + yp;
+  const double t3 = t2 + zm;
+  const double t4 = t3 + zp;
+  const double t5 = six * c;
+  const double t6 = t4 - t5;
+  const double lap = dxinv2 * t6;
+  return lap;
+}
+
+/* tests/mlir_tests/conversion_tests/apply-3d-27pt.mlir: 26 neighbours summed in dim-0-major
+ * order (di, dj, dk ascending, centre skipped), left to right */
+static inline float body_lap3d27(const float *u, int64_t i, int64_t j, int64_t k, int64_t n1, int64_t n2) {
+  const float c = u[IDX3(i, j, k, n1, n2)];
+  float s = 0.0f;
+  int first = 1;
+  for (int di = -1; di <= 1; ++di)
+    for (int dj = -1; dj <= 1; ++dj)
+      for (int dk = -1; dk <= 1; ++dk) {
+        if (di == 0 && dj == 0 && dk == 0) continue;
+        const float a = u[IDX3(i + di, j + dj, k + dk, n1, n2)];
+        if (first) { s = a; first = 0; }   /* %s0 = addf %ammm, %ammz starts from the first value */
+        else s = s + a;
+      }
+  const float c26 = 26.0f;
+  const float dxinv2 = 0.015625f;
+  const float t0 = c26 * c;
+  const float t1 = s - t0;
+  const float lap = dxinv2 * t1;
+  return lap;
+}
+
+/* @ac_lap, reference test/smoke_tests/smoke_time_advance.mlir:13-29 */
+static inline double body_lap1d3(const double *u, int64_t i) {
+  const double um1 = u[i - 1];
+  const double u0 = u[i];
+  const double up1 = u[i + 1];
+  const double two = 2.0;
+  const double dxinv2 = 100.0;
+  const double t0 = two * u0;
+  const double t1 = um1 - t0;
+  const double t2 = t1 + up1;
+  const double lap_i = dxinv2 * t2;
+  return lap_i;
+}
+
+/* ---- faithful: what the reference's lowered @entry executes -------------------------------- */
+/* lb/ub: apply.bounds (logical == physical here: every fixture box starts at 0) */
+int ref_entry_lap2d5_f64(double *out, const double *in, int64_t n0, int64_t n1, const int64_t *lb,
+                         const int64_t *ub) {
+  const size_t N = (size_t)n0 * (size_t)n1;
+  double *tmp = (double *)malloc(N * sizeof(double));
+  if (!tmp) return -1;
+  memcpy(tmp, in, N * sizeof(double));
+  for (int64_t i = lb[0]; i < ub[0]; ++i)
+    for (int64_t j = lb[1]; j < ub[1]; ++j) tmp[IDX2(i, j, n1)] = body_lap2d5(in, i, j, n1);
+  memcpy(out, tmp, N * sizeof(double));
+  free(tmp);
+  return 0;
+}
+
+int ref_entry_lap3d7_f64(double *out, const double *in, int64_t n0, int64_t n1, int64_t n2, const int64_t *lb,
+                         const int64_t *ub) {
+  const size_t N = (size_t)n0 * (size_t)n1 * (size_t)n2;
+  double *tmp = (double *)malloc(N * sizeof(double));
+  if (!tmp) return -1;
+  memcpy(tmp, in, N * sizeof(double));
+  for (int64_t i = lb[0]; i < ub[0]; ++i)
+    for (int64_t j = lb[1]; j < ub[1]; ++j)
+      for (int64_t k = lb[2]; k < ub[2]; ++k) tmp[IDX3(i, j, k, n1, n2)] = body_lap3d7(in, i, j, k, n1, n2);
+  memcpy(out, tmp, N * sizeof(double));
+  free(tmp);
+  return 0;
+}
+
+int ref_entry_lap3d27_f32(float *out, const float *in, int64_t n0, int64_t n1, int64_t n2, const int64_t *lb,
+                          const int64_t *ub) {
+  const size_t N = (size_t)n0 * (size_t)n1 * (size_t)n2;
+  float *tmp = (float *)malloc(N * sizeof(float));
+  if (!tmp) return -1;
+  memcpy(tmp, in, N * sizeof(float));
+  for (int64_t i = lb[0]; i < ub[0]; ++i)
+    for (int64_t j = lb[1]; j < ub[1]; ++j)
+      for (int64_t k = lb[2]; k < ub[2]; ++k) tmp[IDX3(i, j, k, n1, n2)] = body_lap3d27(in, i, j, k, n1, n2);
+  memcpy(out, tmp, N * sizeof(float));
+  free(tmp);
+  return 0;
+}
+
+int ref_entry_lap1d3_f64(double *out, const double *in, int64_t n0, const int64_t *lb, const int64_t *ub) {
+  double *tmp = (double *)malloc((size_t)n0 * sizeof(double));
+  if (!tmp) return -1;
+  memcpy(tmp, in, (size_t)n0 * sizeof(double));
+  for (int64_t i = lb[0]; i < ub[0]; ++i) tmp[i] = body_lap1d3(in, i);
+  memcpy(out, tmp, (size_t)n0 * sizeof(double));
+  free(tmp);
+  return 0;
+}
+
+/* ---- fused: single pass, all cores -------------------------------------------------------- */
+int ref_fused_lap2d5_f64(double *out, const double *in, int64_t n0, int64_t n1, const int64_t *lb,
+                         const int64_t *ub) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n0; ++i) {
+    const int in_i = i >= lb[0] && i < ub[0];
+    for (int64_t j = 0; j < n1; ++j) {
+      const int inside = in_i && j >= lb[1] && j < ub[1];
+      out[IDX2(i, j, n1)] = inside ? body_lap2d5(in, i, j, n1) : in[IDX2(i, j, n1)];
+    }
+  }
+  return 0;
+}
+
+int ref_fused_lap3d7_f64(double *out, const double *in, int64_t n0, int64_t n1, int64_t n2, const int64_t *lb,
+                         const int64_t *ub) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n0; ++i) {
+    const int in_i = i >= lb[0] && i < ub[0];
+    for (int64_t j = 0; j < n1; ++j) {
+      const int in_ij = in_i && j >= lb[1] && j < ub[1];
+      for (int64_t k = 0; k < n2; ++k) {
+        const int inside = in_ij && k >= lb[2] && k < ub[2];
+        out[IDX3(i, j, k, n1, n2)] = inside ? body_lap3d7(in, i, j, k, n1, n2) : in[IDX3(i, j, k, n1, n2)];
+      }
+    }
+  }
+  return 0;
+}
+
+int ref_fused_lap3d27_f32(float *out, const float *in, int64_t n0, int64_t n1, int64_t n2, const int64_t *lb,
+                          const int64_t *ub) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < n0; ++i) {
+    const int in_i = i >= lb[0] && i < ub[0];
+    for (int64_t j = 0; j < n1; ++j) {
+      const int in_ij = in_i && j >= lb[1] && j < ub[1];
+      for (int64_t k = 0; k < n2; ++k) {
+        const int inside = in_ij && k >= lb[2] && k < ub[2];
+        out[IDX3(i, j, k, n1, n2)] = inside ? body_lap3d27(in, i, j, k, n1, n2) : in[IDX3(i, j, k, n1, n2)];
+      }
+    }
+  }
+  return 0;
+}
+
+int ref_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* ---- deterministic field, host twin of neptune_hip_fill_hash (apply_common.hpp) ------------- */
+static inline uint64_t mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void ref_fill_hash_f64(double *dst, int64_t count, int64_t index_offset, uint64_t seed) {
+  const uint64_t ms = mix64(seed);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < count; ++i) {
+    const uint64_t h = mix64((uint64_t)(i + index_offset) ^ ms);
+    dst[i] = (double)(h >> 12) * (1.0 / 2251799813685248.0) - 1.0;
+  }
+}
+void ref_fill_hash_f32(float *dst, int64_t count, int64_t index_offset, uint64_t seed) {
+  const uint64_t ms = mix64(seed);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < count; ++i) {
+    const uint64_t h = mix64((uint64_t)(i + index_offset) ^ ms);
+    dst[i] = (float)(h >> 41) * (1.0f / 4194304.0f) - 1.0f;
+  }
+}
