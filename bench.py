@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the NeptuneIR stencil hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W          (N > 1, one rank per GPU)
+
+A "step" is one `neptune_ir.apply` of the 3-D 7-point Laplacian fixture
+(tests/mlir_tests/conversion_tests/apply-3d-7pt.mlir's body) over the whole 1024^3 fp64 field
+-- BASELINE.json's metric configuration -- ping-ponging between two device-resident fields, so
+every step reads what the previous one wrote.  Inputs are resident in HBM before the timed
+region; nothing crosses PCIe inside it.
+
+N > 1: the field is cut into dim-0 slabs (strong scaling: the global problem stays 1024^3),
+each step exchanges one halo plane per neighbour over RCCL/xGMI on a second stream, overlapped
+with the interior update (neptune_hip/slab.py).
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how every field is derived.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
+
+WORKLOADS = {
+    # name: (body name, global shape, element bytes, stencil points)
+    "3d7_1024": ("lap3d7_f64", (1024, 1024, 1024), 8, 7),
+    "3d7_512": ("lap3d7_f64", (512, 512, 512), 8, 7),
+    "2d5_8192": ("lap2d5_f64", (8192, 8192), 8, 5),
+    "2d5_1024": ("lap2d5_f64", (1024, 1024), 8, 5),
+    "3d27_512": ("lap3d27_f32", (512, 512, 512), 4, 27),
+}
+ORACLE_FN = {"lap3d7_f64": "lap3d7_f64", "lap2d5_f64": "lap2d5_f64", "lap3d27_f32": "lap3d27_f32"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="3d7_1024", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "march"])
+    ap.add_argument("--variant", type=int, default=-1, help="march tile variant (-1 = library default)")
+    ap.add_argument("--chunk", type=int, default=0, help="march planes per workgroup (0 = auto)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos before the interior (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-planes", type=int, default=0, help="dim-0 extent of the CPU sample (0 = auto)")
+    ap.add_argument("--hbm-traffic-bytes", type=float, default=None,
+                    help="per-launch HBM bytes from a separate rocprofv3 --pmc pass (reported as roofline.traffic)")
+    return ap.parse_args()
+
+
+def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
+    """Time the C oracle's faithful restatement of the reference lowering (1 thread, 3 passes,
+    fresh malloc per apply) on a bounded dim-0 sample of the same workload, plus the fused
+    all-core variant.  Test infrastructure used as the *baseline*, never as the product."""
+    import numpy as np
+    lib_path = REPO / "oracle" / "_build" / "liboracle.so"
+    if not lib_path.exists():
+        return None
+    lib = C.CDLL(str(lib_path))
+    nd = len(shape)
+    ct = C.c_double if elem_bytes == 8 else C.c_float
+    dt = np.float64 if elem_bytes == 8 else np.float32
+    plane_cells = 1
+    for n in shape[1:]:
+        plane_cells *= n
+    if sample_planes <= 0:
+        # ~5e8 cells keeps the whole CPU leg (fill + scalar 3-pass run + 3 fused runs) in the 10-30 s band
+        sample_planes = max(3, min(shape[0], int(5.0e8 // plane_cells)))
+    sshape = (sample_planes,) + tuple(shape[1:])
+    count = sample_planes * plane_cells
+    fill = lib.ref_fill_hash_f64 if elem_bytes == 8 else lib.ref_fill_hash_f32
+    fill.argtypes = [C.POINTER(ct), C.c_int64, C.c_int64, C.c_uint64]
+    fill.restype = None
+    u = np.empty(sshape, dt)
+    out = np.zeros(sshape, dt)   # touch the destination like the reference driver does (out[i] = 0)
+    fill(u.ctypes.data_as(C.POINTER(ct)), count, 0, 2024)
+    lb = (C.c_int64 * nd)(*([1] * nd))
+    ub = (C.c_int64 * nd)(*[n - 1 for n in sshape])
+    updates = 1
+    for n in sshape:
+        updates *= (n - 2)
+    res = {}
+    for variant in ("entry", "fused"):
+        fn = getattr(lib, f"ref_{variant}_{ORACLE_FN[body_name]}")
+        fn.restype = C.c_int
+        fn.argtypes = [C.POINTER(ct), C.POINTER(ct)] + [C.c_int64] * nd + [C.POINTER(C.c_int64)] * 2
+        best = None
+        reps = 1 if variant == "entry" else 3
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc = fn(out.ctypes.data_as(C.POINTER(ct)), u.ctypes.data_as(C.POINTER(ct)),
+                    *[C.c_int64(n) for n in sshape], lb, ub)
+            dtm = time.perf_counter() - t0
+            assert rc == 0
+            best = dtm if best is None else min(best, dtm)
+        res[variant] = (updates / best, best)
+    lib.ref_num_threads.restype = C.c_int
+    threads = int(lib.ref_num_threads())
+    dims = "x".join(str(n) for n in sshape)
+    return {
+        "value": res["entry"][0], "unit": "cell-updates/s", "cores": 1, "kind": "port",
+        "sample": f"{dims} slab of the workload (same plane size), faithful restatement of the reference "
+                  f"lowering: malloc + copy-through + scalar loop nest + store copy, {res['entry'][1]:.2f} s",
+        "fused_all_cores": {"value": res["fused"][0], "cores": threads, "seconds": res["fused"][1]},
+        "host_cores": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no HIP device visible; the NeptuneIR HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    from neptune_hip import _capi, apply as nh_apply, fields, slab as slab_mod
+    lib = _capi.load()          # ImportError if libneptune_hip.so is missing: fail loudly
+    lib.neptune_hip_init(local_rank)
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    body_name, gshape, esize, points = WORKLOADS[args.workload]
+    body = nh_apply.BODY_BY_NAME[body_name]
+    dtype = nh_apply.BODY_DTYPE[body]
+    rank_nd = len(gshape)
+    gbox = ([0] * rank_nd, list(gshape))
+    gbounds = ([1] * rank_nd, [n - 1 for n in gshape])
+    kernel = {"auto": _capi.KERNEL_AUTO, "direct": _capi.KERNEL_DIRECT, "march": _capi.KERNEL_MARCH}[args.kernel]
+    cfg = nh_apply.make_cfg(kernel, max(args.variant, 0), args.chunk)
+
+    sl = slab_mod.decompose(gbox, 1, rank, world)
+    # two device-resident local fields (owned planes + ghost planes), ping-pong
+    plane_cells = 1
+    for n in gshape[1:]:
+        plane_cells *= n
+    bufs = [fields.DeviceField(sl.local_lb, sl.local_ub, dtype) for _ in range(2)]
+    # global deterministic field: value depends on the GLOBAL linear index, so every rank count
+    # works on the same data
+    bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
+    bufs[1].tensor.zero_()
+    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap)
+    stream_ptr = fields.current_stream_ptr()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step(s):
+        op(bufs[s % 2], bufs[(s + 1) % 2])
+
+    for s in range(args.warmup):
+        step(s)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+
+    ev0, ev1 = lib.neptune_hip_event_create(), lib.neptune_hip_event_create()
+    t0 = time.perf_counter()
+    lib.neptune_hip_event_record(ev0, stream_ptr)
+    for s in range(args.warmup, args.warmup + args.steps):
+        step(s)
+    lib.neptune_hip_event_record(ev1, stream_ptr)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev_ms = lib.neptune_hip_event_elapsed_ms(ev0, ev1)
+
+    if world > 1:
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, ev_ms = float(t[0]), float(t[1])
+
+    # guard against a silently dead run: the result must be finite and must have changed
+    probe = bufs[(args.warmup + args.steps) % 2].tensor
+    lo, hi = sl.owned_planes()
+    mid = probe[(lo + hi) // 2]
+    assert bool(torch.isfinite(mid).all()), "non-finite values in the result"
+    assert float(mid.abs().max()) > 0.0, "result is identically zero"
+
+    if rank == 0:
+        cells = 1
+        updates = 1
+        for n in gshape:
+            cells *= n
+            updates *= (n - 2)
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = updates * args.steps / elapsed
+        # roofline of the dominant kernel.  Algorithmic bytes per launch = 2 * N * sizeof(T): every
+        # input cell read once, every result cell written once; one launch covers
+        # this rank's owned cells.  Duration = HIP-event time on the launch stream / launches.
+        own_cells = sl.n_own * plane_cells
+        if world == 1:
+            alg_bytes = 2.0 * own_cells * esize
+            kern_ms = ev_ms / args.steps
+        else:
+            alg_bytes = 2.0 * own_cells * esize
+            kern_ms = ev_ms / args.steps  # per step on this rank's compute stream (interior + edges + waits)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        plan = nh_apply.plan_builtin(body, [bufs[0]], bufs[1], op.bounds, region=op._own_region(), cfg=cfg)
+        vcount = lib.neptune_hip_march_variant_count(rank_nd)
+        vname = lib.neptune_hip_march_variant_name(rank_nd, cfg.variant).decode() if plan == _capi.KERNEL_MARCH else ""
+        out = {
+            "metric": "stencil-cell-updates/s",
+            "value": value,
+            "unit": "cell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64" if esize == 8 else "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{rank_nd}-D {points}-point Laplacian apply, "
+                            f"{'x'.join(str(n) for n in gshape)} {'fp64' if esize == 8 else 'fp32'}, "
+                            f"interior bounds, copy-through boundary, ping-pong fields",
+                "fixture": {"lap3d7_f64": "apply-3d-7pt.mlir", "lap2d5_f64": "apply-2d-5pt.mlir",
+                            "lap3d27_f32": "apply-3d-27pt.mlir"}[body_name],
+                "decomposition": f"dim-0 slabs x{world}, 1 halo plane/neighbour over RCCL"
+                                 + ("" if args.no_overlap else ", overlapped with interior") if world > 1 else "single GPU",
+                "kernel": lib.neptune_hip_kernel_name(plan).decode(),
+                "variant": vname,
+                "chunk": args.chunk,
+            },
+            "hbm_GBps": achieved * world if world > 1 else achieved,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": args.hbm_traffic_bytes,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": kern_ms,
+                "per": "launch (whole field)" if world == 1 else "step on rank 0 (interior + edge launches)",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(body_name, gshape, esize, args.cpu_sample_planes)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    lib.neptune_hip_event_destroy(ev0)
+    lib.neptune_hip_event_destroy(ev1)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+"""Slab decomposition of one field across the GPUs of a node + halo exchange over RCCL.
+
+The reference has no domain decomposition at all (every PETSc object is on PETSC_COMM_SELF,
+lib/Runtime/PETSc/NeptunePETScRuntime.cpp:136,244,257); this is the multi-GPU face of the
+`neptune_ir.apply` hot path.  Cell updates are independent given a halo of r = max |offset|
+cells, so a field is cut into slabs along dim 0 (the slowest dim: a halo is then r contiguous
+planes, one contiguous run of memory, no packing):
+
+    rank g owns global planes [start_g, stop_g); its local buffer also holds r ghost planes
+    from each existing neighbour:   local box = [start_g - r_lo, stop_g + r_hi) x full x full
+    (r_lo = r if g > 0 else 0, r_hi = r if g < G-1 else 0 -- no ghosts beyond the global
+    boundary, where the apply's copy-through semantics hold instead of a periodic wrap,
+    DataflowLowering.cpp:382-410 has none).
+
+One sharded apply (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI):
+
+    comm stream   : send first/last r owned planes of the INPUT to the neighbours,
+                    receive their planes into the ghost planes          (grouped isend/irecv)
+    compute stream: interior planes (those whose neighbourhood is already local)   -- overlaps
+    compute stream: after the exchange, the r edge planes on each side that needed ghosts
+
+Everything here is geometry + torch.distributed plumbing; the cell updates themselves run in
+libneptune_hip.so (GPU) -- or, in the CPU tests of this module, in the oracle.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+Box = Tuple[Sequence[int], Sequence[int]]
+
+
+@dataclass(frozen=True)
+class Slab:
+    """what rank `rank` of `world` holds of a global field box [glb, gub)"""
+    rank: int
+    world: int
+    radius: int
+    glb: Tuple[int, ...]
+    gub: Tuple[int, ...]
+    start: int   # first owned global plane (logical coordinate along dim 0)
+    stop: int    # one past the last owned plane
+    r_lo: int    # ghost planes below / above
+    r_hi: int
+
+    # ---- boxes ---------------------------------------------------------------------------
+    @property
+    def local_lb(self) -> Tuple[int, ...]:
+        return (self.start - self.r_lo,) + tuple(self.glb[1:])
+
+    @property
+    def local_ub(self) -> Tuple[int, ...]:
+        return (self.stop + self.r_hi,) + tuple(self.gub[1:])
+
+    @property
+    def local_shape(self) -> Tuple[int, ...]:
+        return tuple(u - l for l, u in zip(self.local_lb, self.local_ub))
+
+    @property
+    def n_own(self) -> int:
+        return self.stop - self.start
+
+    def owned_planes(self) -> Tuple[int, int]:
+        """physical plane range of the owned part inside the local buffer"""
+        return self.r_lo, self.r_lo + self.n_own
+
+    def clip_bounds(self, bounds: Box) -> Box:
+        """apply.bounds restricted to the planes this rank owns"""
+        lb, ub = list(bounds[0]), list(bounds[1])
+        lb[0] = max(lb[0], self.start)
+        ub[0] = min(ub[0], self.stop)
+        if ub[0] < lb[0]:
+            ub[0] = lb[0]
+        return lb, ub
+
+    def regions(self) -> Tuple[Optional[Box], List[Box]]:
+        """(interior, edges) as result-physical boxes of the local buffer.  Interior planes
+        need no ghost data; edge planes (r on each side that has a neighbour) do."""
+        shape = self.local_shape
+        lo, hi = self.owned_planes()
+        i_lo = lo + (self.radius if self.r_lo else 0)
+        i_hi = hi - (self.radius if self.r_hi else 0)
+        full = lambda a, b: ([a] + [0] * (len(shape) - 1), [b] + list(shape[1:]))
+        if i_hi <= i_lo:  # slab thinner than two halos: everything waits for the exchange
+            return None, [full(lo, hi)]
+        edges = []
+        if self.r_lo:
+            edges.append(full(lo, i_lo))
+        if self.r_hi:
+            edges.append(full(i_hi, hi))
+        return full(i_lo, i_hi), edges
+
+
+def decompose(global_box: Box, radius: int, rank: int, world: int) -> Slab:
+    glb, gub = tuple(int(x) for x in global_box[0]), tuple(int(x) for x in global_box[1])
+    n0 = gub[0] - glb[0]
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    if n0 < world:
+        raise ValueError(f"cannot cut {n0} planes into {world} slabs")
+    base, rem = divmod(n0, world)
+    start = glb[0] + rank * base + min(rank, rem)
+    stop = start + base + (1 if rank < rem else 0)
+    if world > 1 and base < radius:
+        raise ValueError("slab thinner than the halo radius")
+    return Slab(rank, world, radius, glb, gub, start, stop, radius if rank > 0 else 0,
+                radius if rank < world - 1 else 0)
+
+
+def halo_ops(slab: Slab, t: torch.Tensor, group=None) -> List[dist.P2POp]:
+    """isend/irecv descriptors that fill the ghost planes of local buffer `t` (any device):
+    planes are contiguous dim-0 slices, sent and received in place."""
+    if tuple(t.shape) != slab.local_shape or not t.is_contiguous():
+        raise ValueError("tensor is not this slab's dense local buffer")
+    r = slab.radius
+    lo, hi = slab.owned_planes()
+    ops: List[dist.P2POp] = []
+    if slab.r_lo:  # neighbour below (rank-1): my first r owned planes go down, its last r come up
+        ops.append(dist.P2POp(dist.isend, t[lo:lo + r], slab.rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, t[lo - r:lo], slab.rank - 1, group))
+    if slab.r_hi:
+        ops.append(dist.P2POp(dist.isend, t[hi - r:hi], slab.rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, t[hi:hi + r], slab.rank + 1, group))
+    return ops
+
+
+def exchange_halos(slab: Slab, t: torch.Tensor, group=None) -> list:
+    """start the exchange; returns the work handles (call .wait() on each)"""
+    ops = halo_ops(slab, t, group)
+    if not ops:
+        return []
+    return dist.batch_isend_irecv(ops)
+
+
+class ShardedApply:
+    """One built-in apply over a slab-decomposed field, exchange overlapped with the interior."""
+
+    def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True):
+        from . import apply as _apply  # GPU path only
+        self._apply = _apply
+        self.slab = slab
+        self.body = body
+        self.bounds = slab.clip_bounds(bounds)
+        self.cfg = cfg
+        self.overlap = overlap
+        self.interior, self.edges = slab.regions()
+        self.compute = torch.cuda.current_stream()
+        self.comm = torch.cuda.Stream()
+        self.ready = torch.cuda.Event()
+        self.halo_done = torch.cuda.Event()
+
+    def __call__(self, fin, fout) -> None:
+        slab = self.slab
+        st = int(self.compute.cuda_stream)
+        if slab.world == 1:
+            self._apply.apply_builtin(self.body, [fin], fout, self.bounds, region=self._own_region(), cfg=self.cfg,
+                                      stream=st)
+            return
+        # 1. exchange the input's edge planes on the comm stream, once the input is complete
+        self.ready.record(self.compute)
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ready)
+            works = exchange_halos(slab, fin.tensor)
+            for w in works:
+                w.wait()              # stream-ordered: the comm stream waits for RCCL, the host does not
+            self.halo_done.record(self.comm)
+        if not self.overlap:
+            self.compute.wait_event(self.halo_done)
+        # 2. interior planes overlap the exchange
+        if self.interior is not None:
+            self._apply.apply_builtin(self.body, [fin], fout, self.bounds, region=self.interior, cfg=self.cfg,
+                                      stream=st)
+        # 3. edge planes once the ghosts have landed
+        self.compute.wait_event(self.halo_done)
+        for reg in self.edges:
+            self._apply.apply_builtin(self.body, [fin], fout, self.bounds, region=reg, cfg=self.cfg, stream=st)
+
+    def _own_region(self) -> Box:
+        lo, hi = self.slab.owned_planes()
+        shape = self.slab.local_shape
+        return [lo] + [0] * (len(shape) - 1), [hi] + list(shape[1:])

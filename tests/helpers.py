@@ -61,13 +61,13 @@ def mismatch_report(a: np.ndarray, b: np.ndarray, limit=5) -> str:
     return "\n".join(lines)
 
 
-def oracle_module(kind, shape):
-    return oracle.Module.parse(stencil_module(kind, shape))
+def oracle_module(kind, shape, origin=None, bounds=None):
+    return oracle.Module.parse(stencil_module(kind, shape, origin, bounds))
 
 
-def oracle_entry(kind, u: np.ndarray) -> np.ndarray:
+def oracle_entry(kind, u: np.ndarray, origin=None, bounds=None) -> np.ndarray:
     """result of the fixture's @entry(out, in) on input u, per the numpy oracle"""
-    m = oracle_module(kind, u.shape)
+    m = oracle_module(kind, u.shape, origin, bounds)
     out = np.zeros_like(u)
     r = m.call("entry", out, u)
     assert r is out

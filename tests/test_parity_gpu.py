@@ -1,0 +1,275 @@
+"""Parity proper: the HIP path, called through the C ABI, against the oracle on the same inputs.
+
+Bar: BIT-EXACT for every case (integer-like discipline on floating point: the device code is
+built -ffp-contract=off and evaluates the body's ops in textual order, exactly like the
+reference's FMA-free scalar lowering).  No tolerance is used anywhere in this file.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import bits_equal, mismatch_report
+
+pytestmark = pytest.mark.gpu
+
+KIND_BODY = {"2d5": "lap2d5_f64", "3d7": "lap3d7_f64", "3d27": "lap3d27_f32"}
+KIND_DTYPE = {"2d5": np.float64, "3d7": np.float64, "3d27": np.float32}
+
+
+@pytest.fixture(scope="module")
+def nh(built_libs):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    from neptune_hip import _capi, apply, fields
+    lib = _capi.load()
+    assert lib.neptune_hip_available() == 1
+    lib.neptune_hip_init(0)
+    assert lib.neptune_hip_arch().decode().startswith("gfx950"), lib.neptune_hip_arch()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.capi, ns.apply, ns.fields, ns.lib, ns.torch = _capi, apply, fields, lib, torch
+    return ns
+
+
+def _run(nh, kind, u, cfg=None, origin=None, bounds=None, region=None, prefill=None):
+    body = nh.apply.BODY_BY_NAME[KIND_BODY[kind]]
+    origin = [0] * u.ndim if origin is None else origin
+    fin = nh.fields.DeviceField.from_numpy(u, origin)
+    fout = nh.fields.DeviceField.empty_like(fin)
+    if prefill is not None:
+        fout.tensor.fill_(prefill)
+    if bounds is None:
+        bounds = ([o + 1 for o in origin], [o + n - 1 for o, n in zip(origin, u.shape)])
+    nh.apply.apply_builtin(body, [fin], fout, bounds, region=region, cfg=cfg)
+    nh.torch.cuda.synchronize()
+    return fout.numpy()
+
+
+def _variants(nh, rank):
+    return range(nh.lib.neptune_hip_march_variant_count(rank))
+
+
+SHAPES = {
+    "2d5": [(3, 3), (5, 8), (17, 130), (40, 256), (33, 1024), (64, 1280), (9, 37)],
+    "3d7": [(3, 3, 4), (8, 8, 8), (6, 7, 130), (20, 18, 128), (33, 17, 256), (12, 70, 384), (5, 9, 11)],
+    "3d27": [(3, 3, 4), (8, 8, 8), (6, 7, 132), (20, 18, 256), (9, 33, 512), (5, 9, 11)],
+}
+
+
+@pytest.mark.parametrize("kind", ["2d5", "3d7", "3d27"])
+def test_direct_kernel_bit_exact(nh, kind):
+    for shape in SHAPES[kind]:
+        u = helpers.hash_field(shape, KIND_DTYPE[kind], seed=5)
+        want = helpers.oracle_entry(kind, u)
+        got = _run(nh, kind, u, nh.apply.make_cfg(nh.capi.KERNEL_DIRECT))
+        assert bits_equal(got, want), f"{kind} {shape} direct\n" + mismatch_report(got, want)
+
+
+@pytest.mark.parametrize("kind", ["2d5", "3d7", "3d27"])
+def test_march_kernel_every_variant_bit_exact(nh, kind):
+    vk = 16 // np.dtype(KIND_DTYPE[kind]).itemsize
+    rank = len(SHAPES[kind][0])
+    for shape in SHAPES[kind]:
+        if shape[-1] % vk:
+            continue  # march declines rows that are not a multiple of the 16-byte lane vector
+        u = helpers.hash_field(shape, KIND_DTYPE[kind], seed=6)
+        want = helpers.oracle_entry(kind, u)
+        for v in _variants(nh, rank):
+            for chunk in (0, 1, 3):
+                got = _run(nh, kind, u, nh.apply.make_cfg(nh.capi.KERNEL_MARCH, v, chunk), prefill=7.0)
+                name = nh.lib.neptune_hip_march_variant_name(rank, v).decode()
+                assert bits_equal(got, want), f"{kind} {shape} march {name} chunk={chunk}\n" + mismatch_report(got, want)
+
+
+def test_auto_plan_runs_march_on_wide_rows_and_direct_on_narrow(nh):
+    u = helpers.hash_field((12, 10, 256), np.float64, seed=2)
+    fin = nh.fields.DeviceField.from_numpy(u)
+    fout = nh.fields.DeviceField.empty_like(fin)
+    b = ([1, 1, 1], [11, 9, 255])
+    assert nh.apply.plan_builtin(nh.capi.BODY_LAP3D7_F64, [fin], fout, b) == nh.capi.KERNEL_MARCH
+    v = helpers.hash_field((12, 10, 30), np.float64, seed=2)
+    fin2 = nh.fields.DeviceField.from_numpy(v)
+    fout2 = nh.fields.DeviceField.empty_like(fin2)
+    assert nh.apply.plan_builtin(nh.capi.BODY_LAP3D7_F64, [fin2], fout2, ([1, 1, 1], [11, 9, 29])) == nh.capi.KERNEL_DIRECT
+
+
+@pytest.mark.parametrize("kernel", ["direct", "march"])
+def test_sub_box_bounds_and_shifted_logical_origin(nh, kernel):
+    """copy-through outside apply.bounds, logical origin != 0 (DataflowLowering.cpp:367-369,401-404,437-440)"""
+    k = nh.capi.KERNEL_DIRECT if kernel == "direct" else nh.capi.KERNEL_MARCH
+    u = helpers.hash_field((14, 12, 136), np.float64, seed=9)
+    origin = [5, -3, 7]
+    bounds = ([7, -1, 10], [16, 6, 139])  # strictly inside; leaves thick copy-through margins
+    want = helpers.oracle_entry("3d7", u, origin, bounds)
+    got = _run(nh, "3d7", u, nh.apply.make_cfg(k), origin, bounds)
+    assert bits_equal(got, want), mismatch_report(got, want)
+    # margins are input 0, bit for bit
+    assert bits_equal(got[0], u[0]) and bits_equal(got[:, :2, :], u[:, :2, :])
+    u2 = helpers.hash_field((21, 264), np.float64, seed=10)
+    want2 = helpers.oracle_entry("2d5", u2, [100, -50], ([103, -40], [119, 200]))
+    got2 = _run(nh, "2d5", u2, nh.apply.make_cfg(k), [100, -50], ([103, -40], [119, 200]))
+    assert bits_equal(got2, want2), mismatch_report(got2, want2)
+    # empty bounds: pure copy-through
+    got3 = _run(nh, "2d5", u2, nh.apply.make_cfg(k), [0, 0], ([4, 4], [4, 9]))
+    assert bits_equal(got3, u2)
+
+
+@pytest.mark.parametrize("kernel", ["direct", "march"])
+def test_regions_tile_one_apply_without_touching_other_cells(nh, kernel):
+    """the slab decomposition launches edge planes and interior separately: the union must equal
+    one whole-field apply and cells outside a region must keep their old value"""
+    k = nh.capi.KERNEL_DIRECT if kernel == "direct" else nh.capi.KERNEL_MARCH
+    shape = (18, 10, 128)
+    u = helpers.hash_field(shape, np.float64, seed=12)
+    want = helpers.oracle_entry("3d7", u)
+    body = nh.capi.BODY_LAP3D7_F64
+    fin = nh.fields.DeviceField.from_numpy(u)
+    fout = nh.fields.DeviceField.empty_like(fin)
+    fout.tensor.fill_(-777.0)
+    bounds = ([1, 1, 1], [17, 9, 127])
+    cfg = nh.apply.make_cfg(k)
+    full = lambda lo, hi: ([lo, 0, 0], [hi, shape[1], shape[2]])
+    nh.apply.apply_builtin(body, [fin], fout, bounds, region=full(0, 2), cfg=cfg)
+    nh.torch.cuda.synchronize()
+    part = fout.numpy()
+    assert bits_equal(part[:2], want[:2]) and np.all(part[2:] == -777.0)
+    nh.apply.apply_builtin(body, [fin], fout, bounds, region=full(16, 18), cfg=cfg)
+    nh.apply.apply_builtin(body, [fin], fout, bounds, region=full(2, 16), cfg=cfg)
+    nh.apply.apply_builtin(body, [fin], fout, bounds, region=full(5, 5), cfg=cfg)   # empty region: no-op
+    nh.torch.cuda.synchronize()
+    got = fout.numpy()
+    assert bits_equal(got, want), mismatch_report(got, want)
+
+
+def test_reference_smoke_known_answers_on_the_device(nh):
+    """KAT-1 / KAT-1b: @ac_lap of the reference's smoke_time_advance.mlir, n = 16, driver input"""
+    doc = helpers.load_kats()
+    for k in doc["kats"]:
+        if k["symbol"] != "kat_lap":
+            continue
+        u = np.array([float.fromhex(h) for h in k["inputs"][0]])
+        want = np.array([float.fromhex(h) for h in k["expected"]])
+        fin = nh.fields.DeviceField.from_numpy(u)
+        fout = nh.fields.DeviceField.empty_like(fin)
+        nh.apply.apply_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fout, ([1], [15]))
+        nh.torch.cuda.synchronize()
+        assert bits_equal(fout.numpy(), want), k["name"]
+
+
+def test_plan_errors_surface_before_any_launch(nh):
+    u = np.arange(1, 5, dtype=np.float64)
+    fin = nh.fields.DeviceField.from_numpy(u)
+    fout = nh.fields.DeviceField.empty_like(fin)
+    # reference smoke_apply.mlir: offsets +-1 over the full range -> out of bounds
+    with pytest.raises(nh.capi.NeptuneHipError, match="EOOB"):
+        nh.apply.apply_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fout, ([0], [4]))
+    # result aliasing an input (the reference always materialises a fresh buffer)
+    with pytest.raises(nh.capi.NeptuneHipError, match="EINVAL"):
+        nh.apply.apply_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fin, ([1], [3]))
+
+
+def test_store_full_and_box(nh):
+    s = helpers.hash_field((6, 5), np.float64, seed=3)
+    fs = nh.fields.DeviceField.from_numpy(s, (2, 0))
+    fd = nh.fields.DeviceField((0, -1), (10, 6), nh.capi.F64)
+    fd.tensor.zero_()
+    nh.apply.store(fs, fd, ([3, 1], [7, 4]))
+    nh.torch.cuda.synchronize()
+    want = np.zeros((10, 7))
+    want[3:7, 2:5] = s[1:5, 1:4]
+    assert bits_equal(fd.numpy(), want)
+    f2 = nh.fields.DeviceField.empty_like(fs)
+    nh.apply.store(fs, f2)
+    nh.torch.cuda.synchronize()
+    assert bits_equal(f2.numpy(), s)
+    # 3-D f32 box, empty box, and a box leaving the destination
+    s3 = helpers.hash_field((4, 6, 10), np.float32, seed=4)
+    f3 = nh.fields.DeviceField.from_numpy(s3)
+    d3 = nh.fields.DeviceField((-1, -1, -1), (5, 7, 11), nh.capi.F32)
+    d3.tensor.fill_(9.0)
+    nh.apply.store(f3, d3, ([1, 2, 3], [3, 5, 9]))
+    nh.apply.store(f3, d3, ([1, 2, 3], [1, 5, 9]))
+    nh.torch.cuda.synchronize()
+    want3 = np.full((6, 8, 12), 9.0, np.float32)
+    want3[2:4, 3:6, 4:10] = s3[1:3, 2:5, 3:9]
+    assert bits_equal(d3.numpy(), want3)
+    with pytest.raises(nh.capi.NeptuneHipError, match="EOOB"):
+        nh.apply.store(f3, d3, ([0, 0, 0], [4, 6, 11]))
+
+
+def test_device_fill_matches_host_twin_and_mismatch_counter(nh):
+    for dt, code in ((np.float64, nh.capi.F64), (np.float32, nh.capi.F32)):
+        f = nh.fields.DeviceField.hashed((7, 9, 33), code, seed=77, index_offset=1000)
+        nh.torch.cuda.synchronize()
+        assert bits_equal(f.numpy(), helpers.hash_field((7, 9, 33), dt, 77, 1000))
+        g = nh.fields.DeviceField.hashed((7, 9, 33), code, seed=77, index_offset=1000)
+        assert nh.apply.count_mismatch(f, g) == 0
+        g.tensor.view(-1)[5] += 1
+        g.tensor.view(-1)[500] = float("nan")
+        assert nh.apply.count_mismatch(f, g) == 2
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: too big for the CPU oracle as a whole, so parity is checked through
+#   (a) march kernel == direct kernel on every cell (two independent device implementations),
+#   (b) oracle parity on sampled planes / row bands (3 input planes suffice for one output plane),
+#   (c) copy-through faces equal the input bit for bit.
+# ---------------------------------------------------------------------------------------------
+def _check_planes_3d(nh, kind, fin, fout, planes):
+    n0 = fin.shape[0]
+    for i in planes:
+        if i == 0 or i == n0 - 1:
+            assert bits_equal(fout.planes(i, i + 1), fin.planes(i, i + 1)), f"plane {i}: copy-through"
+            continue
+        slab = fin.planes(i - 1, i + 2)
+        want = helpers.oracle_entry(kind, slab)[1]
+        got = fout.planes(i, i + 1)[0]
+        assert bits_equal(got, want), f"plane {i}\n" + mismatch_report(got, want)
+
+
+@pytest.mark.parametrize("kind,shape,code", [("3d7", (1024, 1024, 1024), 0), ("3d7", (512, 512, 512), 0),
+                                             ("3d27", (512, 512, 512), 1)])
+def test_full_size_3d(nh, kind, shape, code):
+    body = nh.apply.BODY_BY_NAME[KIND_BODY[kind]]
+    fin = nh.fields.DeviceField.hashed(shape, code, seed=2024)
+    f_m = nh.fields.DeviceField.empty_like(fin)
+    f_d = nh.fields.DeviceField.empty_like(fin)
+    bounds = ([1, 1, 1], [n - 1 for n in shape])
+    assert nh.apply.plan_builtin(body, [fin], f_m, bounds) == nh.capi.KERNEL_MARCH
+    nh.apply.apply_builtin(body, [fin], f_m, bounds)
+    nh.apply.apply_builtin(body, [fin], f_d, bounds, cfg=nh.apply.make_cfg(nh.capi.KERNEL_DIRECT))
+    assert nh.apply.count_mismatch(f_m, f_d) == 0
+    n0 = shape[0]
+    _check_planes_3d(nh, kind, fin, f_m, [0, 1, 2, n0 // 2 - 1, n0 // 2, n0 - 2, n0 - 1, 127, 128, 129])
+    del f_d, f_m, fin
+    nh.torch.cuda.empty_cache()
+
+
+def test_full_size_2d_8192(nh):
+    shape = (8192, 8192)
+    fin = nh.fields.DeviceField.hashed(shape, nh.capi.F64, seed=8192)
+    f_m = nh.fields.DeviceField.empty_like(fin)
+    f_d = nh.fields.DeviceField.empty_like(fin)
+    bounds = ([1, 1], [8191, 8191])
+    body = nh.capi.BODY_LAP2D5_F64
+    assert nh.apply.plan_builtin(body, [fin], f_m, bounds) == nh.capi.KERNEL_MARCH
+    nh.apply.apply_builtin(body, [fin], f_m, bounds)
+    nh.apply.apply_builtin(body, [fin], f_d, bounds, cfg=nh.apply.make_cfg(nh.capi.KERNEL_DIRECT))
+    assert nh.apply.count_mismatch(f_m, f_d) == 0
+    # the whole field fits the numpy oracle (512 MiB): full parity
+    got = f_m.numpy()
+    want = helpers.oracle_entry("2d5", fin.numpy())
+    assert bits_equal(got, want), mismatch_report(got, want)
+
+
+def test_config1_1024x1024_fixture_geometry(nh):
+    """BASELINE.json configs[0]: apply-2d-5pt.mlir, 1024x1024 f64 (the CPU-runnable case)"""
+    u = helpers.hash_field((1024, 1024), np.float64, seed=1)
+    want = helpers.oracle_entry("2d5", u)
+    got = _run(nh, "2d5", u)
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(helpers.c_oracle_entry("2d5", u), want)

@@ -75,8 +75,12 @@ def _body(kind):
     raise KeyError(kind)
 
 
-def stencil_module(kind, shape):
-    """NeptuneIR module text for fixture `kind` on a field of the given shape (interior bounds)."""
+def stencil_module(kind, shape, origin=None, bounds=None):
+    """NeptuneIR module text for fixture `kind` on a field of the given shape.
+
+    origin : logical lower corner of the field box (default all zeros)
+    bounds : (lb, ub) of the apply in logical coordinates (default: the interior, one cell in
+             from every face)"""
     rank, elem, opname, _, _, title = KINDS[kind]
     shape = [int(x) for x in shape]
     if len(shape) != rank:
@@ -84,10 +88,13 @@ def stencil_module(kind, shape):
     if min(shape) < 3:
         raise ValueError("every extent must be >= 3 (one interior cell)")
     accesses, body_lines = _body(kind)
-    lb0 = ", ".join(["0"] * rank)
-    ub0 = ", ".join(str(n) for n in shape)
-    lbi = ", ".join(["1"] * rank)
-    ubi = ", ".join(str(n - 1) for n in shape)
+    origin = [0] * rank if origin is None else [int(x) for x in origin]
+    if bounds is None:
+        bounds = ([o + 1 for o in origin], [o + n - 1 for o, n in zip(origin, shape)])
+    lb0 = ", ".join(str(o) for o in origin)
+    ub0 = ", ".join(str(o + n) for o, n in zip(origin, shape))
+    lbi = ", ".join(str(int(x)) for x in bounds[0])
+    ubi = ", ".join(str(int(x)) for x in bounds[1])
     mr = "x".join(["?"] * rank) + "x" + elem
     idx = ", ".join(f"%i{d}: index" for d in range(rank))
     dims = "x".join(str(n) for n in shape) if len(set(shape)) > 1 else f"{shape[0]}^{rank}"
