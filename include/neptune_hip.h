@@ -217,9 +217,12 @@ int64_t neptune_hip_count_mismatch(int dtype, const void *a, const void *b, int6
 double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t *g,
                                       const void *const *in, void *out, void *stream,
                                       const neptune_hip_launch_cfg_t *cfg, int warmup, int reps);
-/* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling. */
-double neptune_hip_time_copy(void *dst, const void *src, size_t bytes, void *stream, int warmup,
-                             int reps);
+/* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling.
+ * mode selects the copy kernel shape (0 .. neptune_hip_copy_mode_count()-1: grid-stride, or
+ * 1/2/4/8 loads in flight per lane with optional non-temporal loads/stores). */
+double neptune_hip_time_copy(void *dst, const void *src, size_t bytes, void *stream, int mode,
+                             int warmup, int reps);
+int neptune_hip_copy_mode_count(void);
 
 /* HIP events for callers that time a stream themselves (bench.py). */
 void *neptune_hip_event_create(void);

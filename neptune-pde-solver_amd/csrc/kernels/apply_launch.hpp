@@ -95,38 +95,52 @@ inline void to_axes(const int64_t* src, int64_t dst[3], int64_t fill) {
 struct MarchVariant {
   int RJ, WJ, WK;
   bool dpp, nt;
+  int PF;
+  bool ntl;
   const char* name;
 };
-// rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B
-constexpr MarchVariant kMarch3[] = {
-    {4, 4, 1, false, false, "rj4_wj4_wk1"},
+// rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
+// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, name)
 #if NEPTUNE_HIP_FULL_VARIANTS
-    {4, 1, 4, false, false, "rj4_wj1_wk4"},
-    {2, 4, 1, false, false, "rj2_wj4_wk1"},
-    {2, 2, 2, false, false, "rj2_wj2_wk2"},
-    {8, 2, 1, false, false, "rj8_wj2_wk1"},
-    {1, 4, 1, false, false, "rj1_wj4_wk1"},
-    {4, 4, 1, true, false, "rj4_wj4_wk1_dpp"},
-    {4, 4, 1, false, true, "rj4_wj4_wk1_nt"},
-    {4, 4, 1, true, true, "rj4_wj4_wk1_dpp_nt"},
-    {2, 4, 1, true, true, "rj2_wj4_wk1_dpp_nt"},
-    {4, 2, 2, true, true, "rj4_wj2_wk2_dpp_nt"},
-    {8, 2, 1, true, true, "rj8_wj2_wk1_dpp_nt"},
-#endif
-};
+#define NEPTUNE_MARCH3_VARIANTS(X)                \
+  X(0, 4, 4, 1, true, true, 1, false, "rj4_wj4_wk1_pf1")        \
+  X(1, 4, 4, 1, false, false, 1, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(2, 4, 4, 1, true, true, 2, false, "rj4_wj4_wk1_pf2")        \
+  X(3, 2, 4, 1, true, true, 2, false, "rj2_wj4_wk1_pf2")        \
+  X(4, 2, 4, 1, true, true, 3, false, "rj2_wj4_wk1_pf3")        \
+  X(5, 8, 2, 1, true, true, 1, false, "rj8_wj2_wk1_pf1")        \
+  X(6, 8, 2, 1, true, true, 2, false, "rj8_wj2_wk1_pf2")        \
+  X(7, 4, 2, 2, true, true, 2, false, "rj4_wj2_wk2_pf2")        \
+  X(8, 4, 4, 1, true, true, 2, true, "rj4_wj4_wk1_pf2_ntl")     \
+  X(9, 2, 4, 1, true, true, 1, false, "rj2_wj4_wk1_pf1")        \
+  X(10, 1, 4, 1, true, true, 4, false, "rj1_wj4_wk1_pf4")       \
+  X(11, 4, 4, 1, true, true, 3, false, "rj4_wj4_wk1_pf3")       \
+  X(12, 2, 4, 1, true, true, 4, false, "rj2_wj4_wk1_pf4")       \
+  X(13, 4, 1, 4, true, true, 2, false, "rj4_wj1_wk4_pf2")       \
+  X(14, 2, 2, 2, true, true, 3, false, "rj2_wj2_wk2_pf3")       \
+  X(15, 4, 8, 1, true, true, 2, false, "rj4_wj8_wk1_pf2")
 // rank 2: J has extent 1, a workgroup is WK waves side by side
-constexpr MarchVariant kMarch2[] = {
-    {1, 1, 4, false, false, "wk4"},
-#if NEPTUNE_HIP_FULL_VARIANTS
-    {1, 1, 2, false, false, "wk2"},
-    {1, 1, 1, false, false, "wk1"},
-    {1, 1, 8, false, false, "wk8"},
-    {1, 1, 4, true, false, "wk4_dpp"},
-    {1, 1, 4, false, true, "wk4_nt"},
-    {1, 1, 4, true, true, "wk4_dpp_nt"},
-    {1, 1, 1, true, true, "wk1_dpp_nt"},
+#define NEPTUNE_MARCH2_VARIANTS(X)                \
+  X(0, 1, 1, 4, true, true, 1, false, "wk4_pf1")  \
+  X(1, 1, 1, 4, false, false, 1, false, "wk4_pf1_shfl_plainst") \
+  X(2, 1, 1, 4, true, true, 2, false, "wk4_pf2")  \
+  X(3, 1, 1, 4, true, true, 4, false, "wk4_pf4")  \
+  X(4, 1, 1, 1, true, true, 2, false, "wk1_pf2")  \
+  X(5, 1, 1, 1, true, true, 4, false, "wk1_pf4")  \
+  X(6, 1, 1, 1, true, true, 8, false, "wk1_pf8")  \
+  X(7, 1, 1, 2, true, true, 4, false, "wk2_pf4")  \
+  X(8, 1, 1, 4, true, true, 4, true, "wk4_pf4_ntl") \
+  X(9, 1, 1, 4, true, true, 8, false, "wk4_pf8")  \
+  X(10, 1, 1, 8, true, true, 4, false, "wk8_pf4")
+#else
+#define NEPTUNE_MARCH3_VARIANTS(X) X(0, 4, 4, 1, true, true, 1, false, "rj4_wj4_wk1_pf1")
+#define NEPTUNE_MARCH2_VARIANTS(X) X(0, 1, 1, 4, true, true, 1, false, "wk4_pf1")
 #endif
-};
+
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, name) {RJ, WJ, WK, DPP, NT, PF, NTL, name},
+constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
+constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
+#undef NEPTUNE_MV_ROW
 constexpr int kNumMarch3 = sizeof(kMarch3) / sizeof(kMarch3[0]);
 constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
 
@@ -136,10 +150,11 @@ inline const MarchVariant* march_variant(int rank, int v) {
   return rank == 3 ? &kMarch3[v] : &kMarch2[v];
 }
 
-template <class Body, class T, int RANK, int NIN, class FP, int RJ, int WJ, int WK, bool DPP, bool NT>
+template <class Body, class T, int RANK, int NIN, class FP, class TL>
 inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk_req,
                                  hipStream_t stream) {
   constexpr int VK = 16 / sizeof(T);
+  constexpr int WJ = TL::WJ, WK = TL::WK, RJ = TL::RJ;
   const int64_t tileK = (int64_t)WK * kWave * VK, tileJ = (int64_t)WJ * RJ;
   P.nK = (uint32_t)((P.N2 + tileK - 1) / tileK);
   P.nJ = (uint32_t)((P.N1 + tileJ - 1) / tileJ);
@@ -161,7 +176,7 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
     abort();
   }
   P.chunk = (int32_t)chunk;
-  hipLaunchKernelGGL((neptune_apply_march<Body, T, RANK, NIN, FP, RJ, WJ, WK, DPP, NT>), dim3((uint32_t)blocks),
+  hipLaunchKernelGGL((neptune_apply_march<Body, T, RANK, NIN, FP, TL>), dim3((uint32_t)blocks),
                      dim3(kWave * WJ * WK), 0, stream, P, body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
 }
@@ -169,42 +184,16 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
 template <class Body, class T, int RANK, int NIN, class FP>
 inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
                          hipStream_t stream) {
-#define NEPTUNE_MV(RJ, WJ, WK, DPP, NT) \
-  launch_march_variant<Body, T, RANK, NIN, FP, RJ, WJ, WK, DPP, NT>(P, body, planes, chunk, stream)
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, name)                                         \
+  case idx:                                                                                              \
+    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL>>(P, body, planes, chunk, stream); \
+    break;
   if constexpr (RANK == 3) {
-    switch (variant) {
-      default:
-      case 0: NEPTUNE_MV(4, 4, 1, false, false); break;
-#if NEPTUNE_HIP_FULL_VARIANTS
-      case 1: NEPTUNE_MV(4, 1, 4, false, false); break;
-      case 2: NEPTUNE_MV(2, 4, 1, false, false); break;
-      case 3: NEPTUNE_MV(2, 2, 2, false, false); break;
-      case 4: NEPTUNE_MV(8, 2, 1, false, false); break;
-      case 5: NEPTUNE_MV(1, 4, 1, false, false); break;
-      case 6: NEPTUNE_MV(4, 4, 1, true, false); break;
-      case 7: NEPTUNE_MV(4, 4, 1, false, true); break;
-      case 8: NEPTUNE_MV(4, 4, 1, true, true); break;
-      case 9: NEPTUNE_MV(2, 4, 1, true, true); break;
-      case 10: NEPTUNE_MV(4, 2, 2, true, true); break;
-      case 11: NEPTUNE_MV(8, 2, 1, true, true); break;
-#endif
-    }
+    switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }
   } else {
-    switch (variant) {
-      default:
-      case 0: NEPTUNE_MV(1, 1, 4, false, false); break;
-#if NEPTUNE_HIP_FULL_VARIANTS
-      case 1: NEPTUNE_MV(1, 1, 2, false, false); break;
-      case 2: NEPTUNE_MV(1, 1, 1, false, false); break;
-      case 3: NEPTUNE_MV(1, 1, 8, false, false); break;
-      case 4: NEPTUNE_MV(1, 1, 4, true, false); break;
-      case 5: NEPTUNE_MV(1, 1, 4, false, true); break;
-      case 6: NEPTUNE_MV(1, 1, 4, true, true); break;
-      case 7: NEPTUNE_MV(1, 1, 1, true, true); break;
-#endif
-    }
+    switch (variant) { NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }
   }
-#undef NEPTUNE_MV
+#undef NEPTUNE_MV_CASE
 }
 
 // ---- plan + launch ----------------------------------------------------------------------

@@ -147,11 +147,25 @@ struct MarchAcc {
 };
 
 // ---- the kernel ---------------------------------------------------------------------------
+// Tile: compile-time shape of one workgroup's work
 //   RJ    rows per lane            WJ x WK  waves per workgroup along J x K
 //   DPP   wave shifts by DPP (true) or ds_bpermute (false)
 //   NT    non-temporal stores for the result (it is never re-read by this launch)
-template <class Body, class T, int RANK, int NIN, class FP, int RJ, int WJ, int WK, bool DPP, bool NT>
-__global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams<T, NIN> P, Body body) {
+//   PF    prefetch distance: planes of row loads kept in flight per wave.  The kernel is
+//         bound by bytes in flight per CU (HBM latency under load is several microseconds), so
+//         PF trades VGPRs (occupancy) for deeper per-wave queues.
+//   NTL   non-temporal loads for the input rows
+template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_>
+struct Tile {
+  static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_;
+  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_;
+};
+
+template <class Body, class T, int RANK, int NIN, class FP, class TL>
+__global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(MarchParams<T, NIN> P, Body body) {
+  constexpr int RJ = TL::RJ, WJ = TL::WJ, WK = TL::WK, PF = TL::PF;
+  constexpr bool DPP = TL::DPP, NT = TL::NT, NTL = TL::NTL;
+  static_assert(PF >= 1, "prefetch distance");
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
   constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
@@ -218,7 +232,7 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
   V ring[NP][NR];           // live planes of the halo input (row vectors)
   T khl[NPH][NR][NS];       // scalar K halos, left  (wave-uniform)
   T khr[NPH][NR][NS];       // scalar K halos, right
-  V nxt[NR];                // plane in flight
+  V nxt[PF][NR];            // planes in flight (slot ph is consumed by steps i == ph mod PF)
   T nkhl[NR][NS], nkhr[NR][NS];
   V pt[NIN][RJ];            // inputs read at offset 0 only, current plane
   V npt[NIN][RJ];           // ... next plane, in flight
@@ -235,7 +249,9 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
       const char* base = plane_base(P.in[HIN], ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
-        rows[s] = *reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+        const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+        if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
+        else rows[s] = *src;
       });
     }
   };
@@ -279,18 +295,24 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
     in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
   });
 
-  // ---- prologue: planes ib-R0 .. ib+R0-1 into ring[1..NP-1], plane ib+R0 in flight ----
+  // ---- prologue: planes ib-R0 .. ib+R0-1 into ring[1..NP-1]; planes ib+R0 .. ib+R0+PF-1 in flight
   static_for<NP - 1>([&](auto pc) {
     constexpr int p = pc;
-    load_rows(ib - R0 + p, ring[p + 1]);  // shifted down at loop top
+    load_rows(ib - R0 + p, ring[p + 1]);  // shifted down at the top of the first step
     if constexpr (BOX) load_khalos(ib - R0 + p, khl[p + 1], khr[p + 1]);
   });
-  load_rows(ib + R0, nxt);
+  static_for<PF>([&](auto dc) {
+    constexpr int d = dc;
+    load_rows(ib + R0 + d, nxt[d]);
+  });
   load_khalos(ib + HLEAD, nkhl, nkhr);
   load_point_inputs(ib, npt);
 
-  for (int32_t i = ib; i < ie; ++i) {
-    // rotate: ring[p] <- ring[p+1], newest plane <- nxt
+  // one plane step; `slot` (compile-time) names the in-flight buffer holding plane i+R0, so no
+  // register that a load is still writing is ever moved
+  auto step = [&](const int32_t i, auto slot_c) {
+    constexpr int slot = slot_c;
+    // rotate: ring[p] <- ring[p+1], newest plane <- nxt[slot]
     static_for<NP - 1>([&](auto pc) {
       constexpr int p = pc;
       static_for<NR>([&](auto sc) {
@@ -307,7 +329,7 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
     });
     static_for<NR>([&](auto sc) {
       constexpr int s = sc;
-      ring[NP - 1][s] = nxt[s];
+      ring[NP - 1][s] = nxt[slot][s];
       static_for<NS>([&](auto xc) {
         constexpr int x = xc;
         khl[NPH - 1][s][x] = nkhl[s][x];
@@ -318,9 +340,10 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
       constexpr int n = nc;
       static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = npt[n][r]; });
     });
-    // prefetch the next step's newest plane while this one is computed
+    // refill the slot just consumed with the plane PF steps ahead; K halos and offset-0 inputs
+    // are one step ahead
+    if (i + PF < ie) load_rows(i + PF + R0, nxt[slot]);
     if (i + 1 < ie) {
-      load_rows(i + 1 + R0, nxt);
       load_khalos(i + 1 + HLEAD, nkhl, nkhr);
       load_point_inputs(i + 1, npt);
     }
@@ -370,6 +393,13 @@ __global__ __launch_bounds__(kWave* WJ* WK) void neptune_apply_march(MarchParams
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }
+    });
+  };
+
+  for (int32_t i = ib; i < ie; i += PF) {
+    static_for<PF>([&](auto phc) {
+      constexpr int ph = phc;
+      if (i + ph < ie) step(i + ph, phc);
     });
   }
 }

@@ -31,12 +31,34 @@ __global__ __launch_bounds__(256) void neptune_store_box(const T* __restrict__ s
   dst[d] = src[s];
 }
 
-// 16 B per lane streaming copy: the measured HBM ceiling the apply kernels are compared with.
-// Grid-stride; n16 = number of 16-byte words.
+// 16 B per lane streaming copies: the measured HBM ceiling the apply kernels are compared with.
+// n16 = number of 16-byte words.
+//   grid-stride form (mode 0)
 __global__ __launch_bounds__(256) void neptune_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst,
                                                       int64_t n16) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+}
+//   U loads in flight per lane, exact grid, optional non-temporal loads/stores (modes 1..)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <int U, bool NTLD, bool NTST>
+__global__ __launch_bounds__(256) void neptune_copy16_unrolled(const u32x4* __restrict__ src,
+                                                               u32x4* __restrict__ dst, int64_t n16) {
+  const int64_t base = (int64_t)blockIdx.x * (256 * U) + threadIdx.x;
+  u32x4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + (int64_t)u * 256;
+    if (i < n16) v[u] = NTLD ? __builtin_nontemporal_load(src + i) : src[i];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t i = base + (int64_t)u * 256;
+    if (i < n16) {
+      if (NTST) __builtin_nontemporal_store(v[u], dst + i);
+      else dst[i] = v[u];
+    }
+  }
 }
 
 template <class T>

@@ -358,14 +358,28 @@ double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t* 
   return (double)ms / reps;
 }
 
-double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* stream, int warmup, int reps) {
+double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* stream, int mode, int warmup,
+                             int reps) {
   if (!dst || !src || reps <= 0 || bytes % 16 != 0) return -1.0;
   ensure_init();
   hipStream_t st = as_stream(stream);
   const int64_t n16 = (int64_t)(bytes / 16);
-  const uint32_t blocks = 256 * 8;  // 8 workgroups of 256 lanes per CU, grid-stride
+  auto blocks_for = [&](int U) { return (uint32_t)((n16 + 256 * U - 1) / (256 * U)); };
   auto launch = [&] {
-    hipLaunchKernelGGL(neptune_copy16, dim3(blocks), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);
+    const u32x4* s4 = (const u32x4*)src;
+    u32x4* d4 = (u32x4*)dst;
+    switch (mode) {
+      default:
+      case 0:  // grid-stride, 8 workgroups per CU
+        hipLaunchKernelGGL(neptune_copy16, dim3(256 * 8), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n16);
+        break;
+      case 1: hipLaunchKernelGGL((neptune_copy16_unrolled<4, false, false>), dim3(blocks_for(4)), dim3(256), 0, st, s4, d4, n16); break;
+      case 2: hipLaunchKernelGGL((neptune_copy16_unrolled<4, false, true>), dim3(blocks_for(4)), dim3(256), 0, st, s4, d4, n16); break;
+      case 3: hipLaunchKernelGGL((neptune_copy16_unrolled<4, true, true>), dim3(blocks_for(4)), dim3(256), 0, st, s4, d4, n16); break;
+      case 4: hipLaunchKernelGGL((neptune_copy16_unrolled<8, false, true>), dim3(blocks_for(8)), dim3(256), 0, st, s4, d4, n16); break;
+      case 5: hipLaunchKernelGGL((neptune_copy16_unrolled<1, false, true>), dim3(blocks_for(1)), dim3(256), 0, st, s4, d4, n16); break;
+      case 6: hipLaunchKernelGGL((neptune_copy16_unrolled<2, false, true>), dim3(blocks_for(2)), dim3(256), 0, st, s4, d4, n16); break;
+    }
   };
   for (int i = 0; i < warmup; ++i) launch();
   hipEvent_t e0, e1;
@@ -382,6 +396,7 @@ double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* str
   NEPTUNE_HIP_CHECK(hipEventDestroy(e1));
   return (double)ms / reps;
 }
+int neptune_hip_copy_mode_count(void) { return 7; }
 
 void* neptune_hip_event_create(void) {
   ensure_init();

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_bench.sh output directory: per-kernel time stats and PMC sums."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    for key in ("neptune_apply_march", "neptune_apply_direct", "neptune_fill_hash", "neptune_copy16", "neptune_store_box"):
+        if key in name:
+            return key
+    return name[:60]
+
+
+print("# kernel stats (rocprofv3 --kernel-trace --stats)")
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            print(f"{short(row.get('Name', '')):28s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} "
+                  f"min_ns={row.get('MinNs')} max_ns={row.get('MaxNs')} total_ns={row.get('TotalDurationNs')} pct={row.get('Percentage')}")
+print("# per-dispatch durations of the apply kernel (kernel trace)")
+for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
+    durs = []
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            if "neptune_apply" in row.get("Kernel_Name", ""):
+                durs.append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if durs:
+        durs.sort()
+        print(f"n={len(durs)} min={durs[0]} median={durs[len(durs)//2]} max={durs[-1]} mean={sum(durs)/len(durs):.0f} ns")
+print("# PMC counters, summed per kernel over dispatches (then / dispatches)")
+for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(set)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = short(row.get("Kernel_Name", ""))
+                acc[k][row.get("Counter_Name")] += float(row.get("Counter_Value", 0))
+                cnt[k].add(row.get("Dispatch_Id"))
+    for k, counters in acc.items():
+        n = max(1, len(cnt[k]))
+        for c, v in counters.items():
+            print(f"{os.path.basename(d):40s} {k:28s} {c:22s} total={v:.6g} per_dispatch={v / n:.6g} dispatches={n}")

@@ -43,10 +43,11 @@ def main():
         b = fields.DeviceField.empty_like(a)
         nbytes = 2.0 * a.nbytes
         bounds = ([1] * len(shape), [n - 1 for n in shape])
-        ms = lib.neptune_hip_time_copy(b.ptr, a.ptr, a.nbytes, fields.current_stream_ptr(), 2, args.reps)
-        rec = {"workload": wl, "kernel": "copy16", "ms": ms, "GBps": nbytes / ms / 1e6}
-        print(f"{wl:10s} {'copy16':28s} {ms:9.4f} ms {rec['GBps']:8.1f} GB/s", flush=True)
-        fout.write(json.dumps(rec) + "\n")
+        for mode in range(lib.neptune_hip_copy_mode_count()):
+            ms = lib.neptune_hip_time_copy(b.ptr, a.ptr, a.nbytes, fields.current_stream_ptr(), mode, 2, args.reps)
+            rec = {"workload": wl, "kernel": f"copy16_mode{mode}", "ms": ms, "GBps": nbytes / ms / 1e6}
+            print(f"{wl:10s} {rec['kernel']:28s} {ms:9.4f} ms {rec['GBps']:8.1f} GB/s", flush=True)
+            fout.write(json.dumps(rec) + "\n")
         ms = apply.time_builtin(body, [a], b, bounds, apply.make_cfg(_capi.KERNEL_DIRECT), 1, max(2, args.reps // 3))
         rec = {"workload": wl, "kernel": "direct", "ms": ms, "GBps": nbytes / ms / 1e6}
         print(f"{wl:10s} {'direct':28s} {ms:9.4f} ms {rec['GBps']:8.1f} GB/s", flush=True)
