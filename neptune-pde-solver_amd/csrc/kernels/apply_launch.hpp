@@ -96,48 +96,63 @@ struct MarchVariant {
   int RJ, WJ, WK;
   bool dpp, nt;
   int PF;
-  bool ntl;
+  bool ntl, ldsj;
   const char* name;
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, name)
+// Variant 0 is the default (best measured on MI355X for the 1024^3 fp64 7-point apply and
+// the 512^3 fp32 27-point apply, sweep of round 1: profiles/r01_sweep.txt); the others stay
+// compiled into the runtime library for tools/sweep.py and for the parity tests, which run
+// every one of them.
+#define NEPTUNE_MARCH3_DEFAULT(X) X(0, 4, 4, 2, true, true, 2, false, true, "rj4_wj4_wk2_pf2_lds")
+#define NEPTUNE_MARCH2_DEFAULT(X) X(0, 1, 1, 4, true, true, 4, false, false, "wk4_pf4")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
-  X(0, 4, 4, 1, true, true, 1, false, "rj4_wj4_wk1_pf1")        \
-  X(1, 4, 4, 1, false, false, 1, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(2, 4, 4, 1, true, true, 2, false, "rj4_wj4_wk1_pf2")        \
-  X(3, 2, 4, 1, true, true, 2, false, "rj2_wj4_wk1_pf2")        \
-  X(4, 2, 4, 1, true, true, 3, false, "rj2_wj4_wk1_pf3")        \
-  X(5, 8, 2, 1, true, true, 1, false, "rj8_wj2_wk1_pf1")        \
-  X(6, 8, 2, 1, true, true, 2, false, "rj8_wj2_wk1_pf2")        \
-  X(7, 4, 2, 2, true, true, 2, false, "rj4_wj2_wk2_pf2")        \
-  X(8, 4, 4, 1, true, true, 2, true, "rj4_wj4_wk1_pf2_ntl")     \
-  X(9, 2, 4, 1, true, true, 1, false, "rj2_wj4_wk1_pf1")        \
-  X(10, 1, 4, 1, true, true, 4, false, "rj1_wj4_wk1_pf4")       \
-  X(11, 4, 4, 1, true, true, 3, false, "rj4_wj4_wk1_pf3")       \
-  X(12, 2, 4, 1, true, true, 4, false, "rj2_wj4_wk1_pf4")       \
-  X(13, 4, 1, 4, true, true, 2, false, "rj4_wj1_wk4_pf2")       \
-  X(14, 2, 2, 2, true, true, 3, false, "rj2_wj2_wk2_pf3")       \
-  X(15, 4, 8, 1, true, true, 2, false, "rj4_wj8_wk1_pf2")
+  NEPTUNE_MARCH3_DEFAULT(X)                                                   \
+  X(1, 4, 4, 1, false, false, 1, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(2, 4, 4, 1, true, true, 2, false, false, "rj4_wj4_wk1_pf2")        \
+  X(3, 2, 4, 1, true, true, 2, false, false, "rj2_wj4_wk1_pf2")        \
+  X(4, 8, 2, 1, true, true, 1, false, false, "rj8_wj2_wk1_pf1")        \
+  X(5, 4, 8, 1, true, true, 2, false, false, "rj4_wj8_wk1_pf2")        \
+  X(6, 4, 4, 1, true, true, 3, false, false, "rj4_wj4_wk1_pf3")        \
+  X(7, 2, 2, 2, true, true, 3, false, false, "rj2_wj2_wk2_pf3")        \
+  X(8, 4, 4, 1, true, true, 1, false, true, "rj4_wj4_wk1_pf1_lds")     \
+  X(9, 4, 4, 1, true, true, 2, false, true, "rj4_wj4_wk1_pf2_lds")     \
+  X(10, 4, 8, 1, true, true, 2, false, true, "rj4_wj8_wk1_pf2_lds")    \
+  X(11, 2, 8, 1, true, true, 2, false, true, "rj2_wj8_wk1_pf2_lds")    \
+  X(12, 2, 8, 1, true, true, 4, false, true, "rj2_wj8_wk1_pf4_lds")    \
+  X(13, 4, 4, 1, true, true, 3, false, true, "rj4_wj4_wk1_pf3_lds")    \
+  X(14, 2, 4, 1, true, true, 3, false, true, "rj2_wj4_wk1_pf3_lds")    \
+  X(15, 4, 4, 1, true, true, 1, false, false, "rj4_wj4_wk1_pf1")       \
+  X(16, 2, 16, 1, true, true, 3, false, true, "rj2_wj16_wk1_pf3_lds")  \
+  X(17, 1, 16, 1, true, true, 4, false, true, "rj1_wj16_wk1_pf4_lds")  \
+  X(18, 8, 4, 1, true, true, 1, false, true, "rj8_wj4_wk1_pf1_lds")    \
+  X(19, 4, 8, 1, true, true, 3, false, true, "rj4_wj8_wk1_pf3_lds")    \
+  X(20, 4, 4, 2, true, true, 3, false, true, "rj4_wj4_wk2_pf3_lds")    \
+  X(21, 8, 4, 2, true, true, 1, false, true, "rj8_wj4_wk2_pf1_lds")    \
+  X(22, 4, 2, 4, true, true, 2, false, true, "rj4_wj2_wk4_pf2_lds")    \
+  X(23, 4, 4, 2, true, true, 1, false, true, "rj4_wj4_wk2_pf1_lds")    \
+  X(24, 4, 4, 2, true, true, 2, true, true, "rj4_wj4_wk2_pf2_ntl_lds")
 // rank 2: J has extent 1, a workgroup is WK waves side by side
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
-  X(0, 1, 1, 4, true, true, 1, false, "wk4_pf1")  \
-  X(1, 1, 1, 4, false, false, 1, false, "wk4_pf1_shfl_plainst") \
-  X(2, 1, 1, 4, true, true, 2, false, "wk4_pf2")  \
-  X(3, 1, 1, 4, true, true, 4, false, "wk4_pf4")  \
-  X(4, 1, 1, 1, true, true, 2, false, "wk1_pf2")  \
-  X(5, 1, 1, 1, true, true, 4, false, "wk1_pf4")  \
-  X(6, 1, 1, 1, true, true, 8, false, "wk1_pf8")  \
-  X(7, 1, 1, 2, true, true, 4, false, "wk2_pf4")  \
-  X(8, 1, 1, 4, true, true, 4, true, "wk4_pf4_ntl") \
-  X(9, 1, 1, 4, true, true, 8, false, "wk4_pf8")  \
-  X(10, 1, 1, 8, true, true, 4, false, "wk8_pf4")
+  NEPTUNE_MARCH2_DEFAULT(X)                                      \
+  X(1, 1, 1, 4, false, false, 1, false, false, "wk4_pf1_shfl_plainst") \
+  X(2, 1, 1, 4, true, true, 2, false, false, "wk4_pf2")  \
+  X(3, 1, 1, 4, true, true, 1, false, false, "wk4_pf1")  \
+  X(4, 1, 1, 1, true, true, 2, false, false, "wk1_pf2")  \
+  X(5, 1, 1, 1, true, true, 4, false, false, "wk1_pf4")  \
+  X(6, 1, 1, 1, true, true, 8, false, false, "wk1_pf8")  \
+  X(7, 1, 1, 2, true, true, 4, false, false, "wk2_pf4")  \
+  X(8, 1, 1, 4, true, true, 4, true, false, "wk4_pf4_ntl") \
+  X(9, 1, 1, 4, true, true, 8, false, false, "wk4_pf8")  \
+  X(10, 1, 1, 8, true, true, 4, false, false, "wk8_pf4")
 #else
-#define NEPTUNE_MARCH3_VARIANTS(X) X(0, 4, 4, 1, true, true, 1, false, "rj4_wj4_wk1_pf1")
-#define NEPTUNE_MARCH2_VARIANTS(X) X(0, 1, 1, 4, true, true, 1, false, "wk4_pf1")
+#define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
+#define NEPTUNE_MARCH2_VARIANTS(X) NEPTUNE_MARCH2_DEFAULT(X)
 #endif
 
-#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, name) {RJ, WJ, WK, DPP, NT, PF, NTL, name},
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name},
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
@@ -161,12 +176,12 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
   int64_t chunk = chunk_req;
   if (chunk <= 0) {
-    // aim for ~2 rounds of 16 waves on each of the 256 CUs; a chunk re-reads 2*R0 planes, so
-    // keep it >= 16 planes
-    const int64_t want_blocks = (2 * 16 * 256) / (WJ * WK);
-    const int64_t nI_want = (want_blocks + tilesJK - 1) / tilesJK;
-    chunk = (planes + nI_want - 1) / (nI_want > 0 ? nI_want : 1);
-    if (chunk < 16) chunk = 16;
+    // Measured on MI355X (profiles/r01_sweep.txt): 64 planes per workgroup for 3-D tiles and 32
+    // rows for 2-D strips balance the 2*R0 planes re-read per chunk against having several
+    // rounds of workgroups per CU; shrink only when the grid would not fill the chip.
+    chunk = RANK == 3 ? 64 : 32;
+    const int64_t min_blocks = 2 * 256;  // two workgroups per CU
+    while (chunk > 8 && ((planes + chunk - 1) / chunk) * tilesJK < min_blocks) chunk /= 2;
   }
   if (chunk > planes) chunk = planes;
   const int64_t nI = (planes + chunk - 1) / chunk;
@@ -184,9 +199,10 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
 template <class Body, class T, int RANK, int NIN, class FP>
 inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
                          hipStream_t stream) {
-#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, name)                                         \
-  case idx:                                                                                              \
-    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL>>(P, body, planes, chunk, stream); \
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name)                                          \
+  case idx:                                                                                                     \
+    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ>>(P, body, planes, chunk, \
+                                                                                           stream);              \
     break;
   if constexpr (RANK == 3) {
     switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }

@@ -155,10 +155,16 @@ struct MarchAcc {
 //         bound by bytes in flight per CU (HBM latency under load is several microseconds), so
 //         PF trades VGPRs (occupancy) for deeper per-wave queues.
 //   NTL   non-temporal loads for the input rows
-template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_>
+//   LDSJ  J-halo rows come from the neighbouring wave of the same workgroup through LDS
+//         instead of a second global load.  Two waves that miss on the same line at almost the
+//         same time are BOTH served from the fabric (measured: every halo-row load of the
+//         all-global form reached the memory side, FETCH = 1.5x the field for RJ = 4), so
+//         sharing through LDS removes real HBM/fabric traffic, not just L2 hits.  Only the
+//         workgroup's outermost rows still come from global memory.
+template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false>
 struct Tile {
   static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_;
-  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_;
+  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_;
 };
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -180,6 +186,12 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   constexpr int HLEAD = BOX ? R0 : 0;  // halos in flight belong to plane i+1+HLEAD
   static_assert(R2 <= VK, "K radius larger than one lane's vector is not supported");
   static_assert(HAS_HALO || (R0 == 0 && R1 == 0 && R2 == 0), "pointwise footprint must have zero radii");
+  // J-halo exchange through LDS needs a vertical neighbour in the workgroup and a J radius that
+  // one neighbour can serve
+  constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && R1 <= RJ && HAS_HALO;
+  constexpr int LROWS = LDSJ ? 2 * R1 : 1;
+  // [double buffer][wave][first R1 own rows | last R1 own rows][lane]: 1 KiB per row
+  __shared__ V lds_rows[LDSJ ? 2 : 1][LDSJ ? WJ * WK : 1][LROWS][LDSJ ? kWave : 1];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -196,7 +208,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // base is a 64-bit pointer.  Wave-uniform values live in SGPRs.
   const int32_t j0 = (int32_t)(jt * (WJ * RJ)) + wj * RJ;              // first own row
   const int32_t kw = (int32_t)((kt * WK + wk) * (uint32_t)(kWave * VK));  // first own column
-  if (j0 >= P.N1 || kw >= P.N2) return;                                 // wave-uniform
+  // Waves whose tile lies outside the field are not retired: every address below is clamped
+  // into the field and their stores are predicated off, so they can keep taking part in the
+  // workgroup barriers of the LDS exchange.
   const int32_t k0 = kw + lane * VK;
   const bool lane_ok = k0 < P.N2;  // N2 % VK == 0, so a lane is entirely in or out
   const uint32_t lane_b = (uint32_t)(lane_ok ? k0 : P.N2 - VK) * (uint32_t)sizeof(T);
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   static_for<NS>([&](auto xc) {
     constexpr int x = xc;
     int32_t kl = kw - R2 + x;
-    kl = kl < 0 ? 0 : kl;
+    kl = kl < 0 ? 0 : (kl >= P.N2 ? P.N2 - 1 : kl);
     int32_t kr = kw_end + x;
     kr = kr >= P.N2 ? P.N2 - 1 : kr;
     khlb[x] = (uint32_t)kl * (uint32_t)sizeof(T);
@@ -244,14 +258,26 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
     return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
   };
-  auto load_rows = [&](int32_t ip, V(&rows)[NR]) {
+  // all_rows = true: fetch the J-halo rows from global memory too (prologue planes, which do
+  // not pass through the LDS exchange)
+  auto load_rows = [&](int32_t ip, V(&rows)[NR], auto all_rows_c) {
+    constexpr bool all_rows = decltype(all_rows_c)::value;
     if constexpr (HAS_HALO) {
       const char* base = plane_base(P.in[HIN], ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
-        const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
-        if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
-        else rows[s] = *src;
+        auto ld = [&] {
+          const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+          if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
+          else rows[s] = *src;
+        };
+        if constexpr (LDSJ && !all_rows && s < R1) {
+          if (wj == 0) ld();           // top rows of the workgroup: no wave above to get them from
+        } else if constexpr (LDSJ && !all_rows && s >= R1 + RJ) {
+          if (wj == WJ - 1) ld();      // bottom rows of the workgroup
+        } else {
+          ld();
+        }
       });
     }
   };
@@ -298,12 +324,12 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // ---- prologue: planes ib-R0 .. ib+R0-1 into ring[1..NP-1]; planes ib+R0 .. ib+R0+PF-1 in flight
   static_for<NP - 1>([&](auto pc) {
     constexpr int p = pc;
-    load_rows(ib - R0 + p, ring[p + 1]);  // shifted down at the top of the first step
+    load_rows(ib - R0 + p, ring[p + 1], std::true_type{});  // shifted down at the top of the first step
     if constexpr (BOX) load_khalos(ib - R0 + p, khl[p + 1], khr[p + 1]);
   });
   static_for<PF>([&](auto dc) {
     constexpr int d = dc;
-    load_rows(ib + R0 + d, nxt[d]);
+    load_rows(ib + R0 + d, nxt[d], std::false_type{});
   });
   load_khalos(ib + HLEAD, nkhl, nkhr);
   load_point_inputs(ib, npt);
@@ -336,13 +362,30 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         khr[NPH - 1][s][x] = nkhr[s][x];
       });
     });
+    if constexpr (LDSJ) {
+      // J-halo rows of the plane that just arrived: publish my first/last R1 own rows, take the
+      // neighbouring waves' rows.  Double-buffered by step parity, one barrier per step.
+      const int buf = (i - ib) & 1;
+      static_for<R1>([&](auto xc) {
+        constexpr int x = xc;
+        lds_rows[buf][w][x][lane] = ring[NP - 1][R1 + x];            // first own rows
+        lds_rows[buf][w][R1 + x][lane] = ring[NP - 1][RJ + x];       // last own rows (s = R1+RJ-R1+x)
+      });
+      __syncthreads();
+      static_for<R1>([&](auto xc) {
+        constexpr int x = xc;
+        // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
+        if (wj > 0) ring[NP - 1][x] = lds_rows[buf][w - WK][R1 + x][lane];
+        if (wj < WJ - 1) ring[NP - 1][R1 + RJ + x] = lds_rows[buf][w + WK][x][lane];
+      });
+    }
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
       static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = npt[n][r]; });
     });
     // refill the slot just consumed with the plane PF steps ahead; K halos and offset-0 inputs
     // are one step ahead
-    if (i + PF < ie) load_rows(i + PF + R0, nxt[slot]);
+    if (i + PF < ie) load_rows(i + PF + R0, nxt[slot], std::false_type{});
     if (i + 1 < ie) {
       load_khalos(i + 1 + HLEAD, nkhl, nkhr);
       load_point_inputs(i + 1, npt);
