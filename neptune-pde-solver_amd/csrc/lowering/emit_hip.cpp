@@ -1,0 +1,571 @@
+// emit_hip.cpp -- the `backend = hip` dataflow lowering: NeptuneIR module -> one HIP translation
+// unit whose host side calls the hand-written stencil kernels.
+//
+// It takes the place of the reference's NeptuneIRDataflowLoweringPass
+// (lib/Passes/DataflowLowering.cpp:739-819, the `backend == gpu` slot at :803-804 that was never
+// wired, lib/Pipeline/NeptuneIRPassesPipeline.cpp:22-26) together with the part of
+// StructureLowering (lib/Passes/StructureLowering.cpp:30-124) it depends on:
+//
+//   linear_opdef / nonlinear_opdef @A      -> exported extern "C" symbol A + internal A__impl
+//   apply_linear / apply_nonlinear @A(x)   -> call of A__impl (device-resident, no staging)
+//   wrap / unwrap / load                   -> aliases                      (:131-159)
+//   apply                                  -> Body functor (one C++ statement per region op, in
+//                                             textual order) + run_apply<Body,...>: ONE kernel that
+//                                             also does the copy-through of input 0 (:258-448)
+//   store                                  -> elided when the producing apply can write straight
+//                                             into the destination field, else a device copy (:165-220)
+//   func.func @entry                       -> exported symbol with expanded memref arguments and a
+//                                             memref struct result (upstream func-to-llvm ABI,
+//                                             NeptuneIRPassesPipeline.cpp:36-40)
+//
+// The arithmetic inside a Body is emitted as written: no reassociation, no contraction (the TU is
+// compiled with -ffp-contract=off), constants as hexadecimal floating literals.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <set>
+#include <sstream>
+
+#include "lowering.h"
+
+namespace neptune_lowering {
+namespace {
+
+std::string cname(const std::string& ssa) {  // %lap_i -> v_lap_i
+  std::string s = "v_";
+  for (size_t i = 1; i < ssa.size(); ++i) s += (std::isalnum((unsigned char)ssa[i]) ? ssa[i] : '_');
+  return s;
+}
+std::string ctype(const std::string& elem) {
+  if (elem == "f64") return "double";
+  if (elem == "f32") return "float";
+  if (elem == "index" || elem == "i64") return "int64_t";
+  if (elem == "i32") return "int32_t";
+  if (elem == "i1") return "bool";
+  return "void";
+}
+int esize(const std::string& elem) { return elem == "f32" ? 4 : 8; }
+std::string dtype_macro(const std::string& elem) { return elem == "f32" ? "NEPTUNE_HIP_F32" : "NEPTUNE_HIP_F64"; }
+
+std::string float_literal(const std::string& lit, const std::string& elem, bool& ok) {
+  ok = true;
+  if (lit.size() > 2 && (lit.compare(0, 2, "0x") == 0 || lit.compare(0, 3, "-0x") == 0)) { ok = false; return ""; }
+  char buf[64];
+  const double d = std::strtod(lit.c_str(), nullptr);
+  if (elem == "f32") {
+    const float f = (float)d;  // MLIR parses the literal as a double and rounds it to f32
+    if (std::isinf(f) || std::isnan(f)) { ok = false; return ""; }
+    snprintf(buf, sizeof(buf), "%af", (double)f);
+  } else {
+    if (std::isinf(d) || std::isnan(d)) { ok = false; return ""; }
+    snprintf(buf, sizeof(buf), "%a", d);
+  }
+  return buf;
+}
+
+std::string box_init(const Bounds& b) {
+  std::ostringstream o;
+  o << "{" << b.rank() << ", {";
+  for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.lb[d] : 0);
+  o << "}, {";
+  for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.ub[d] : 1);
+  o << "}}";
+  return o.str();
+}
+
+struct Footprint {
+  int nin = 0, rank = 0;
+  int radius[4][3];      // all accesses
+  int top_radius[4][3];  // unconditional accesses only; -1 = none
+  bool box = false;
+  int halo_input = -1;
+  bool march_ok = true;
+};
+
+struct Emitter {
+  const Module& m;
+  Diag& diag;
+  LowerInfo& info;
+  std::ostringstream bodies, funcs;
+  int box_counter = 0;
+  std::ostringstream consts;
+  Emitter(const Module& mm, Diag& d, LowerInfo& i) : m(mm), diag(d), info(i) {}
+
+  std::string new_box(const Bounds& b) {
+    std::string name = "kBox" + std::to_string(box_counter++);
+    consts << "static const nl::Box " << name << " = " << box_init(b) << ";\n";
+    return name;
+  }
+
+  // ---- apply region -> Body functor ----------------------------------------------------
+  void scan_accesses(const Block& blk, const std::map<std::string, int>& temp_index, Footprint& fp, bool top) {
+    for (auto& op : blk.ops) {
+      if (op->name == "neptune_ir.access") {
+        const int k = temp_index.at(op->operands[0]);
+        int nz = 0;
+        for (int d = 0; d < fp.rank; ++d) {
+          const int a = (int)std::llabs(op->offsets[d]);
+          if (a) ++nz;
+          if (a > fp.radius[k][d]) fp.radius[k][d] = a;
+          if (top && a > fp.top_radius[k][d]) fp.top_radius[k][d] = a;  // starts at -1: offset 0 counts
+        }
+        if (nz > 1) fp.box = true;
+      }
+      for (auto& r : op->regions) scan_accesses(*r, temp_index, fp, false);
+    }
+  }
+
+  bool emit_region_ops(const Block& blk, std::ostringstream& o, const std::string& ind,
+                       const std::map<std::string, int>& temp_index, const std::map<std::string, int>& index_arg,
+                       const std::vector<std::string>* if_results) {
+    for (auto& opp : blk.ops) {
+      const Op& op = *opp;
+      const std::string& n = op.name;
+      auto val = [&](const std::string& v) -> std::string {
+        auto it = index_arg.find(v);
+        if (it != index_arg.end()) return "a.template idx<" + std::to_string(it->second) + ">()";
+        return cname(v);
+      };
+      auto res = [&]() { return cname(op.results.at(0)); };
+      if (n == "neptune_ir.access") {
+        o << ind << "const " << ctype(op.types[1].elem) << " " << res() << " = a.template get<" << temp_index.at(op.operands[0]);
+        for (auto off : op.offsets) o << ", " << off;
+        o << ">();\n";
+      } else if (n == "arith.constant") {
+        const Type& t = op.types[0];
+        if (t.elem == "f64" || t.elem == "f32") {
+          bool ok;
+          std::string lit = float_literal(op.literal, t.elem, ok);
+          if (!ok) { diag.fail(op.line, "unsupported floating-point constant '" + op.literal + "'"); return false; }
+          o << ind << "const " << ctype(t.elem) << " " << res() << " = " << lit << ";  // " << op.literal << "\n";
+        } else if (t.elem == "i1") {
+          o << ind << "const bool " << res() << " = " << ((op.literal == "true" || op.literal == "1") ? "true" : "false") << ";\n";
+        } else {
+          o << ind << "const " << ctype(t.elem) << " " << res() << " = (" << ctype(t.elem) << ")" << op.literal << "LL;\n";
+        }
+      } else if (n == "arith.addf" || n == "arith.subf" || n == "arith.mulf" || n == "arith.divf" || n == "arith.addi" ||
+                 n == "arith.subi" || n == "arith.muli") {
+        const char* sym = (n.find("add") != std::string::npos) ? "+" : (n.find("sub") != std::string::npos) ? "-"
+                          : (n.find("mul") != std::string::npos) ? "*" : "/";
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = " << val(op.operands[0]) << " " << sym << " "
+          << val(op.operands[1]) << ";\n";
+      } else if (n == "arith.andi" || n == "arith.ori" || n == "arith.xori") {
+        const bool b1 = op.types[0].elem == "i1";
+        const char* sym = n == "arith.andi" ? (b1 ? "&&" : "&") : n == "arith.ori" ? (b1 ? "||" : "|") : (b1 ? "!=" : "^");
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = " << val(op.operands[0]) << " " << sym << " "
+          << val(op.operands[1]) << ";\n";
+      } else if (n == "arith.negf") {
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = -" << val(op.operands[0]) << ";\n";
+      } else if (n == "arith.maximumf" || n == "arith.minimumf" || n == "arith.maxnumf" || n == "arith.minnumf") {
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(6) << "("
+          << val(op.operands[0]) << ", " << val(op.operands[1]) << ");\n";
+      } else if (n == "math.sqrt" || n == "math.absf") {
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(5) << "("
+          << val(op.operands[0]) << ");\n";
+      } else if (n == "arith.cmpf") {
+        const std::string a = val(op.operands[0]), b = val(op.operands[1]), &p = op.predicate;
+        std::string e;
+        if (p == "oeq") e = a + " == " + b; else if (p == "ogt") e = a + " > " + b; else if (p == "oge") e = a + " >= " + b;
+        else if (p == "olt") e = a + " < " + b; else if (p == "ole") e = a + " <= " + b;
+        else if (p == "one") e = "(" + a + " < " + b + " || " + a + " > " + b + ")";
+        else if (p == "ord") e = "(" + a + " == " + a + " && " + b + " == " + b + ")";
+        else if (p == "ueq") e = "!(" + a + " < " + b + " || " + a + " > " + b + ")";
+        else if (p == "ugt") e = "!(" + a + " <= " + b + ")"; else if (p == "uge") e = "!(" + a + " < " + b + ")";
+        else if (p == "ult") e = "!(" + a + " >= " + b + ")"; else if (p == "ule") e = "!(" + a + " > " + b + ")";
+        else if (p == "une") e = a + " != " + b; else e = "(" + a + " != " + a + " || " + b + " != " + b + ")";
+        o << ind << "const bool " << res() << " = " << e << ";\n";
+      } else if (n == "arith.cmpi") {
+        const std::string &p = op.predicate;
+        const bool uns = p[0] == 'u';
+        const std::string ct = ctype(op.types[0].elem);
+        const std::string cast = uns ? "(uint64_t)" : "";
+        std::string sym = (p == "eq") ? "==" : (p == "ne") ? "!=" : (p.substr(1) == "lt") ? "<" : (p.substr(1) == "le") ? "<="
+                          : (p.substr(1) == "gt") ? ">" : ">=";
+        o << ind << "const bool " << res() << " = " << cast << val(op.operands[0]) << " " << sym << " " << cast
+          << val(op.operands[1]) << ";\n";
+        (void)ct;
+      } else if (n == "arith.select") {
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = " << val(op.operands[0]) << " ? "
+          << val(op.operands[1]) << " : " << val(op.operands[2]) << ";\n";
+      } else if (n == "arith.index_cast" || n == "arith.sitofp" || n == "arith.fptosi" || n == "arith.extf" ||
+                 n == "arith.truncf" || n == "arith.extsi" || n == "arith.trunci") {
+        o << ind << "const " << ctype(op.types[1].elem) << " " << res() << " = (" << ctype(op.types[1].elem) << ")"
+          << val(op.operands[0]) << ";\n";
+      } else if (n == "arith.uitofp") {
+        o << ind << "const " << ctype(op.types[1].elem) << " " << res() << " = (" << ctype(op.types[1].elem) << ")(uint64_t)"
+          << val(op.operands[0]) << ";\n";
+      } else if (n == "scf.if") {
+        for (size_t r = 0; r < op.results.size(); ++r) o << ind << ctype(op.types[r].elem) << " " << cname(op.results[r]) << ";\n";
+        o << ind << "if (" << val(op.operands[0]) << ") {\n";
+        if (!emit_region_ops(*op.regions[0], o, ind + "  ", temp_index, index_arg, &op.results)) return false;
+        o << ind << "}";
+        if (op.regions.size() > 1) {
+          o << " else {\n";
+          if (!emit_region_ops(*op.regions[1], o, ind + "  ", temp_index, index_arg, &op.results)) return false;
+          o << ind << "}";
+        }
+        o << "\n";
+      } else if (n == "scf.yield") {
+        for (size_t r = 0; r < op.operands.size() && if_results; ++r)
+          o << ind << cname((*if_results)[r]) << " = " << val(op.operands[r]) << ";\n";
+      } else if (n == "neptune_ir.yield") {
+        o << ind << "return " << val(op.operands[0]) << ";\n";
+      } else {
+        diag.fail(op.line, "cannot emit '" + n + "'");
+        return false;
+      }
+    }
+    return true;
+  }
+
+  bool emit_body(const Op& apply, const std::string& tag, Footprint& fp) {
+    const Block& blk = *apply.regions[0];
+    const Bounds& b = apply.attrs.at("bounds").bounds;
+    const int rank = b.rank();
+    const int nin = (int)apply.operands.size();
+    const Type& res = apply.types[nin];
+    if (rank > 3) { diag.fail(apply.line, "apply of rank " + std::to_string(rank) + " (the HIP backend supports rank 1..3)"); return false; }
+    if (nin > 4) { diag.fail(apply.line, "apply with more than 4 inputs"); return false; }
+    if (res.elem != "f64" && res.elem != "f32") { diag.fail(apply.line, "apply element type " + res.elem + " (f64 and f32 are supported)"); return false; }
+    for (int k = 0; k < nin; ++k)
+      if (apply.types[k].elem != res.elem) { diag.fail(apply.line, "apply inputs of mixed element types"); return false; }
+    fp.nin = nin;
+    fp.rank = rank;
+    for (int k = 0; k < 4; ++k)
+      for (int d = 0; d < 3; ++d) { fp.radius[k][d] = 0; fp.top_radius[k][d] = -1; }
+    std::map<std::string, int> temp_index, index_arg;
+    for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d;
+    for (int k = 0; k < nin; ++k) temp_index[blk.args[rank + k].name] = k;
+    // inputs never read unconditionally keep top_radius -1 ("not accessed": nothing to check)
+    scan_accesses(blk, temp_index, fp, true);
+    // rank mapping onto the kernel's (I,J,K) axes, see apply_common.hpp AxisMap
+    int halo_inputs = 0;
+    for (int k = 0; k < nin; ++k) {
+      bool any = false;
+      for (int d = 0; d < rank; ++d) any = any || fp.radius[k][d] > 0;
+      if (any) { ++halo_inputs; fp.halo_input = k; }
+    }
+    int R[3] = {0, 0, 0};
+    if (fp.halo_input >= 0) {
+      const int* r = fp.radius[fp.halo_input];
+      if (rank == 3) { R[0] = r[0]; R[1] = r[1]; R[2] = r[2]; }
+      else if (rank == 2) { R[0] = r[0]; R[2] = r[1]; }
+      else { R[2] = r[0]; }
+    }
+    const int vk = 16 / esize(res.elem);
+    fp.march_ok = rank >= 2 && halo_inputs <= 1 && R[0] <= 1 && R[1] <= 1 && R[2] <= 1 && R[2] <= vk;
+    if (halo_inputs > 1) fp.halo_input = -1, R[0] = R[1] = R[2] = 0;
+    if (!fp.march_ok) { fp.halo_input = halo_inputs == 1 ? fp.halo_input : -1; }
+
+    std::ostringstream& o = bodies;
+    o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
+    o << "struct Body_" << tag << " {\n";
+    o << "  template <class A>\n  __device__ __forceinline__ " << ctype(res.elem) << " operator()(const A& a) const {\n";
+    if (!emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr)) return false;
+    o << "  }\n};\n";
+    o << "using FP_" << tag << " = neptune_hip::Footprint<" << (fp.march_ok ? fp.halo_input : -1) << ", "
+      << (fp.march_ok ? R[0] : 0) << ", " << (fp.march_ok ? R[1] : 0) << ", " << (fp.march_ok ? R[2] : 0) << ", "
+      << ((fp.box && fp.march_ok) ? "true" : "false") << ", " << (fp.march_ok ? "true" : "false") << ">;\n";
+    o << "static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
+    for (int k = 0; k < 4; ++k) {
+      o << (k ? ", {" : "{");
+      for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (k < nin && d < rank ? fp.top_radius[k][d] : -1);
+      o << "}";
+    }
+    o << "};\n\n";
+    return true;
+  }
+
+  // ---- functions -----------------------------------------------------------------------
+  struct ValueInfo {
+    Type type;
+    int root_arg = -1;  // >= 0: aliases function argument #root_arg
+    int def_index = -1;
+    int uses = 0;
+  };
+
+  bool lowerable(const Function& f, std::string& why, int depth = 0) {
+    if (depth > 32) { why = "recursive opdef calls"; return false; }
+    for (auto& op : f.body.ops)
+      if (op->opaque) { why = "contains '" + op->name + "' (solver / time-stepping op: stays on the host path)"; return false; }
+    if (f.result_types.size() > 1) { why = "more than one result"; return false; }
+    for (auto& t : f.arg_types)
+      if (!(t.kind == TypeKind::MemRef || t.is_tempish())) { why = "argument of type " + t.str() + " (only memref / temp / field arguments are lowered)"; return false; }
+    for (auto& t : f.result_types)
+      if (!(t.kind == TypeKind::MemRef || t.is_tempish())) { why = "result of type " + t.str(); return false; }
+    for (auto& t : f.arg_types) {
+      if (t.rank() < 1 || t.rank() > 3) { why = "rank " + std::to_string(t.rank()) + " argument"; return false; }
+      if (t.elem != "f64" && t.elem != "f32") { why = "element type " + t.elem; return false; }
+    }
+    // every callee must be lowerable too
+    for (auto& op : f.body.ops)
+      if (!op->callee.empty()) {
+        const Function* c = m.find(op->callee);
+        std::string w2;
+        if (!c || !lowerable(*c, w2, depth + 1)) { why = "calls @" + op->callee + " which is not lowered"; return false; }
+      }
+    return true;
+  }
+
+  bool emit_function(const Function& f) {
+    std::map<std::string, ValueInfo> vals;
+    const int nargs = (int)f.arg_types.size();
+    for (int i = 0; i < nargs; ++i) {
+      ValueInfo vi;
+      vi.type = f.arg_types[i];
+      vi.root_arg = i;
+      vals[f.body.args[i].name] = vi;
+    }
+    // use counts + definitions
+    for (size_t oi = 0; oi < f.body.ops.size(); ++oi)
+      for (auto& v : f.body.ops[oi]->operands) vals[v].uses++;
+    // which producer may write straight into which destination
+    std::map<int, std::string> dest_of;  // producer op index -> C expression of the destination Val*
+    int returned_producer = -1;
+    std::map<std::string, int> def_at;
+    for (size_t oi = 0; oi < f.body.ops.size(); ++oi)
+      for (auto& r : f.body.ops[oi]->results) def_at[r] = (int)oi;
+    for (size_t oi = 0; oi < f.body.ops.size(); ++oi) {
+      const Op& op = *f.body.ops[oi];
+      auto producer_of = [&](const std::string& v) -> int {
+        auto it = def_at.find(v);
+        if (it == def_at.end()) return -1;
+        const Op& p = *f.body.ops[it->second];
+        if (p.name == "neptune_ir.apply" || !p.callee.empty()) return it->second;
+        return -1;
+      };
+      if (op.name == "neptune_ir.store" && !op.attrs.count("bounds")) {
+        const int p = producer_of(op.operands[0]);
+        const std::string& field = op.operands[1];
+        const bool field_before = !def_at.count(field) || def_at[field] < p;  // function args precede everything
+        if (p >= 0 && vals[op.operands[0]].uses == 1 && field_before) {
+          bool clean = true;  // nothing between producer and store may observe the field
+          for (int j = p + 1; j < (int)oi; ++j) {
+            const std::string& nm = f.body.ops[j]->name;
+            if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "arith.constant")) clean = false;
+          }
+          if (clean) dest_of[p] = "&" + cname(field);
+        }
+      }
+      if ((op.name == "neptune_ir.return" || op.name == "func.return" || op.name == "return") && op.operands.size() == 1) {
+        const int p = producer_of(op.operands[0]);
+        if (p >= 0 && vals[op.operands[0]].uses == 1) returned_producer = p;
+      }
+    }
+
+    std::ostringstream o;
+    const std::string impl = f.name + "__impl";
+    o << "// ---- @" << f.name << " (line " << f.line << ") ----\n";
+    o << "static nl::Val " << impl << "(nl::Scope& sc";
+    for (int i = 0; i < nargs; ++i) o << ", const nl::Val& " << cname(f.body.args[i].name);
+    o << ", const nl::Val* dest, int* ret_arg) {\n";
+    o << "  (void)dest; if (ret_arg) *ret_arg = -1;\n";
+    int apply_counter = 0;
+    for (size_t oi = 0; oi < f.body.ops.size(); ++oi) {
+      const Op& op = *f.body.ops[oi];
+      const std::string& n = op.name;
+      if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load") {
+        ValueInfo vi;
+        vi.type = op.types[1];
+        vi.root_arg = vals[op.operands[0]].root_arg;
+        vi.uses = vals[op.results[0]].uses;
+        vals[op.results[0]] = vi;
+        Bounds b;
+        if (op.types[1].is_tempish()) b = op.types[1].bounds;
+        o << "  // " << n << " " << op.operands[0] << "\n";
+        if (op.types[1].is_tempish()) {
+          o << "  const nl::Val " << cname(op.results[0]) << " = sc.alias(" << cname(op.operands[0]) << ", " << new_box(b)
+            << ", \"" << n << "\");\n";
+        } else {  // unwrap -> memref: same buffer, zero-based box
+          Bounds zb = op.types[0].bounds;
+          for (int d = 0; d < zb.rank(); ++d) { zb.ub[d] -= zb.lb[d]; zb.lb[d] = 0; }
+          o << "  const nl::Val " << cname(op.results[0]) << " = sc.alias(" << cname(op.operands[0]) << ", " << new_box(zb)
+            << ", \"" << n << "\");\n";
+        }
+      } else if (n == "neptune_ir.apply") {
+        const std::string tag = f.name + "_" + std::to_string(apply_counter++);
+        Footprint fp;
+        if (!emit_body(op, tag, fp)) return false;
+        const int nin = (int)op.operands.size();
+        const Type& res = op.types[nin];
+        ValueInfo vi;
+        vi.type = res;
+        vi.uses = vals[op.results[0]].uses;
+        vals[op.results[0]] = vi;
+        std::string dest = "nullptr";
+        if (dest_of.count((int)oi)) dest = dest_of[(int)oi];
+        else if ((int)oi == returned_producer) dest = "dest";
+        o << "  // neptune_ir.apply -> " << op.results[0] << "   (kernel + fused copy-through)\n";
+        o << "  const nl::Val* in_" << tag << "[] = {";
+        for (int k = 0; k < nin; ++k) o << (k ? ", " : "") << "&" << cname(op.operands[k]);
+        o << "};\n";
+        o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<Body_" << tag << ", " << ctype(res.elem) << ", "
+          << res.bounds.rank() << ", " << nin << ", FP_" << tag << ">(sc, Body_" << tag << "{}, " << new_box(res.bounds) << ", "
+          << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ");\n";
+        ApplyInfo ai;
+        ai.function = f.name;
+        ai.tag = tag;
+        ai.rank = fp.rank;
+        ai.num_inputs = fp.nin;
+        ai.march = fp.march_ok;
+        ai.box = fp.box;
+        ai.halo_input = fp.halo_input;
+        info.applies.push_back(ai);
+      } else if (!op.callee.empty()) {
+        const Function* c = m.find(op.callee);
+        ValueInfo vi;
+        vi.type = c->result_types.at(0);
+        vi.uses = vals[op.results[0]].uses;
+        vals[op.results[0]] = vi;
+        std::string dest = "nullptr";
+        if (dest_of.count((int)oi)) dest = dest_of[(int)oi];
+        else if ((int)oi == returned_producer) dest = "dest";
+        o << "  // " << n << " @" << op.callee << "\n";
+        o << "  const nl::Val " << cname(op.results[0]) << " = " << op.callee << "__impl(sc";
+        for (auto& a : op.operands) o << ", " << cname(a);
+        o << ", " << dest << ", nullptr);\n";
+      } else if (n == "neptune_ir.store") {
+        const Type& vt = op.types[0];
+        o << "  // neptune_ir.store " << op.operands[0] << " to " << op.operands[1] << "\n";
+        if (op.attrs.count("bounds")) {
+          std::string bx = new_box(op.attrs.at("bounds").bounds);
+          o << "  nl::run_store(sc, " << cname(op.operands[0]) << ", " << cname(op.operands[1]) << ", &" << bx << ", "
+            << dtype_macro(vt.elem) << ");\n";
+        } else {
+          o << "  nl::run_store(sc, " << cname(op.operands[0]) << ", " << cname(op.operands[1]) << ", nullptr, "
+            << dtype_macro(vt.elem) << ");\n";
+        }
+      } else if (n == "arith.constant") {
+        // scalar constants at function level only feed solver ops, which are not lowered here
+      } else if (n == "neptune_ir.return" || n == "func.return" || n == "return") {
+        if (op.operands.empty()) {
+          o << "  return nl::Val{};\n";
+        } else {
+          const int root = vals[op.operands[0]].root_arg;
+          if (root >= 0) o << "  if (ret_arg) *ret_arg = " << root << ";\n";
+          o << "  return " << cname(op.operands[0]) << ";\n";
+        }
+      }
+    }
+    o << "}\n";
+
+    // exported symbol with the expanded-memref ABI
+    const bool has_res = !f.result_types.empty();
+    const int rrank = has_res ? f.result_types[0].rank() : 0;
+    o << "extern \"C\" " << (has_res ? "NeptuneMemRef" + std::to_string(rrank) + "D" : std::string("void")) << " " << f.name << "(";
+    for (int i = 0; i < nargs; ++i) {
+      const int r = f.arg_types[i].rank();
+      const std::string a = "a" + std::to_string(i);
+      o << (i ? ", " : "") << "void* " << a << "_allocated, void* " << a << "_aligned, int64_t " << a << "_offset";
+      for (int d = 0; d < r; ++d) o << ", int64_t " << a << "_size" << d;
+      for (int d = 0; d < r; ++d) o << ", int64_t " << a << "_stride" << d;
+    }
+    o << ") {\n";
+    o << "  nl::Scope sc(\"" << f.name << "\");\n";
+    for (int i = 0; i < nargs; ++i) {
+      const Type& t = f.arg_types[i];
+      const int r = t.rank();
+      const std::string a = "a" + std::to_string(i);
+      o << "  const int64_t " << a << "_sizes[] = {";
+      for (int d = 0; d < r; ++d) o << (d ? ", " : "") << a << "_size" << d;
+      o << "}, " << a << "_strides[] = {";
+      for (int d = 0; d < r; ++d) o << (d ? ", " : "") << a << "_stride" << d;
+      o << "};\n";
+      o << "  nl::Val m" << i << " = sc.bind_memref(" << r << ", " << esize(t.elem) << ", " << a << "_allocated, " << a
+        << "_aligned, " << a << "_offset, " << a << "_sizes, " << a << "_strides);\n";
+      if (t.is_tempish()) {
+        // opdef arguments are temps of static shape: the descriptor must match (memref.cast ?->static)
+        o << "  m" << i << " = sc.alias(m" << i << ", " << new_box(t.bounds) << ", \"argument " << i << "\");\n";
+      } else {
+        for (int d = 0; d < r; ++d)
+          if (t.shape[d] >= 0)
+            o << "  if (" << a << "_size" << d << " != " << t.shape[d] << ") nl::die(\"" << f.name << "\", \"memref argument " << i
+              << " has the wrong static extent\");\n";
+      }
+    }
+    o << "  int ret_arg = -1;\n";
+    o << "  " << (has_res ? "const nl::Val r = " : "") << impl << "(sc";
+    for (int i = 0; i < nargs; ++i) o << ", m" << i;
+    o << ", nullptr, &ret_arg);\n";
+    o << "  sc.finish();\n";
+    if (has_res) {
+      const std::string mr = "NeptuneMemRef" + std::to_string(rrank) + "D";
+      o << "  " << mr << " out;\n";
+      // result aliases an argument (e.g. @entry returns unwrap of its destination field): hand the
+      // caller's own descriptor back, as the reference does (smoke_apply.mlir:23-25)
+      o << "  switch (ret_arg) {\n";
+      for (int i = 0; i < nargs; ++i) {
+        if (f.arg_types[i].rank() != rrank) continue;
+        const std::string a = "a" + std::to_string(i);
+        o << "    case " << i << ": out.allocated = " << a << "_allocated; out.aligned = " << a << "_aligned; out.offset = " << a
+          << "_offset;";
+        for (int d = 0; d < rrank; ++d) o << " out.sizes[" << d << "] = " << a << "_size" << d << "; out.strides[" << d << "] = " << a << "_stride" << d << ";";
+        o << " return out;\n";
+      }
+      o << "    default: break;\n  }\n";
+      o << "  void* p = sc.export_result(r);\n";
+      o << "  return nl::make_memref<" << rrank << ">(p, r.box);\n";
+    }
+    o << "}\n\n";
+    funcs << o.str();
+    info.lowered.push_back(f.name);
+    Signature sig;
+    sig.name = f.name;
+    auto conv = [](const Type& t) {
+      SigType st;
+      st.kind = t.kind == TypeKind::MemRef ? "memref" : (t.kind == TypeKind::Temp ? "temp" : "field");
+      st.elem = t.elem;
+      st.rank = t.rank();
+      if (t.kind == TypeKind::MemRef) st.shape = t.shape;
+      else {
+        for (int d = 0; d < t.rank(); ++d) { st.shape.push_back(t.bounds.ub[d] - t.bounds.lb[d]); st.lb.push_back(t.bounds.lb[d]); }
+      }
+      return st;
+    };
+    for (auto& t : f.arg_types) sig.args.push_back(conv(t));
+    sig.has_result = has_res;
+    if (has_res) sig.result = conv(f.result_types[0]);
+    info.signatures.push_back(sig);
+    return true;
+  }
+
+  bool run(std::string& out) {
+    // callees before callers: opdefs are emitted in module order, forward declarations cover the rest
+    std::ostringstream fwd;
+    std::vector<const Function*> todo;
+    for (auto& f : m.funcs) {
+      std::string why;
+      if (!lowerable(*f, why)) { info.skipped.push_back({f->name, why}); continue; }
+      todo.push_back(f.get());
+      fwd << "static nl::Val " << f->name << "__impl(nl::Scope& sc";
+      for (size_t i = 0; i < f->arg_types.size(); ++i) fwd << ", const nl::Val&";
+      fwd << ", const nl::Val* dest, int* ret_arg);\n";
+    }
+    for (auto* f : todo)
+      if (!emit_function(*f)) return false;
+    std::ostringstream o;
+    o << "// Generated by the NeptuneIR HIP lowering (neptune-opt --neptuneir-to-hip).  Do not edit.\n"
+      << "// Compile: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared <this file> \\\n"
+      << "//          -I<repo> -L<repo>/neptune-pde-solver_amd/lib -lneptune_hip\n"
+      << "#include \"neptune-pde-solver_amd/csrc/runtime/lowered_runtime.hpp\"\n"
+      << "#include \"neptune-pde-solver_amd/csrc/kernels/body_ops.hpp\"\n\n"
+      << "namespace nl = neptune_hip::lowered;\n\nnamespace {\n\n"
+      << consts.str() << "\n"
+      << bodies.str() << "}  // namespace\n\n"
+      << fwd.str() << "\n"
+      << funcs.str();
+    for (auto& s : info.skipped) o << "// not lowered: @" << s.first << ": " << s.second << "\n";
+    out = o.str();
+    return true;
+  }
+};
+
+}  // namespace
+
+bool lower_to_hip(const Module& m, std::string& out_source, LowerInfo& info, Diag& diag) {
+  Emitter e(m, diag, info);
+  return e.run(out_source) && diag.ok;
+}
+
+}  // namespace neptune_lowering

@@ -1,0 +1,301 @@
+// lowered_runtime.hpp -- host-side support code included by every module the lowering emits.
+//
+// A lowered module exports one extern "C" symbol per func.func / opdef with the reference's
+// calling convention (expanded memref arguments, memref struct result; reference:
+// test/smoke_tests/smoke_apply.sh:39-50, include/Runtime/PETSc/NeptunePETScRuntime.h:22-42).  The
+// helpers here implement what the reference's lowering leaves to malloc/memcpy:
+//
+//   * residency : a memref argument may point to host or to device memory.  Host buffers get a
+//     device shadow (H2D once at entry, D2H at exit if a neptune_ir.store dirtied it), so existing
+//     host drivers and the PETSc MatMult thunk (NeptunePETScRuntime.cpp:182-230) keep working;
+//     device buffers are used in place, which is the fast path (nothing crosses PCIe).
+//   * ownership : an apply result is allocated by the callee and released by the caller
+//     (DataflowLowering.cpp:281; NeptunePETScRuntime.cpp:219-221 `free(yout.allocated)`).  If any
+//     argument was host memory the result is returned in malloc'ed host memory so `free()` works;
+//     otherwise it is device memory to be released with neptune_rt_free().
+//   * aliasing  : wrap / unwrap / load are aliases (DataflowLowering.cpp:131-159); `store
+//     apply(load f) to f` must behave as if the apply had a private result (:281 + :176-179), so an
+//     apply only writes straight into a destination field when that field aliases none of its
+//     inputs -- otherwise it goes through a temporary and a device copy.
+//   * errors    : "[NeptuneRT][HIP] ..." on stderr + abort(), as the reference runtime does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../../include/neptune_hip.h"
+#include "../kernels/apply_launch.hpp"
+
+namespace neptune_hip {
+namespace lowered {
+
+struct Box {
+  int rank;
+  int64_t lb[3], ub[3];
+  int64_t count() const {
+    int64_t n = 1;
+    for (int d = 0; d < rank; ++d) n *= (ub[d] - lb[d]);
+    return n;
+  }
+  bool same_shape(const Box& o) const {
+    if (rank != o.rank) return false;
+    for (int d = 0; d < rank; ++d)
+      if (ub[d] - lb[d] != o.ub[d] - o.lb[d]) return false;
+    return true;
+  }
+};
+
+// a memref / field / temp SSA value at run time
+struct Val {
+  void* dev = nullptr;    // device address of element 0 (dense row-major)
+  int64_t count = 0;      // elements
+  int esize = 8;
+  Box box{};              // logical box; memref values use lb = 0
+  int shadow = -1;        // index of the host-backed argument this value aliases, or -1
+};
+
+struct HostArg {          // a memref argument that arrived in host memory
+  void* host;             // first element (aligned + offset)
+  void* dev;              // its device shadow
+  size_t bytes;
+  bool dirty;             // device copy is newer (a store wrote it): flush at exit
+};
+
+[[noreturn]] inline void die(const char* fn, const char* what) {
+  fprintf(stderr, "[NeptuneRT][HIP] %s: %s\n", fn, what);
+  abort();
+}
+
+class Scope {
+ public:
+  explicit Scope(const char* fn) : fn_(fn) { neptune_hip_init_default(); }
+  ~Scope() {
+    for (void* p : owned_) NEPTUNE_HIP_CHECK(hipFree(p));
+  }
+  const char* name() const { return fn_; }
+  bool host_mode() const { return !host_args_.empty(); }
+  hipStream_t stream() const { return nullptr; }
+
+  // ---- arguments -----------------------------------------------------------------------
+  // memref argument in the expanded ABI; sizes/strides have `rank` entries
+  Val bind_memref(int rank, int esize, void* allocated, void* aligned, int64_t offset, const int64_t* sizes,
+                  const int64_t* strides) {
+    (void)allocated;
+    if (!aligned) die(fn_, "null memref argument");
+    Val v;
+    v.esize = esize;
+    v.box.rank = rank;
+    int64_t expect = 1;
+    v.count = 1;
+    for (int d = rank - 1; d >= 0; --d) {
+      if (sizes[d] <= 0) die(fn_, "memref argument with a non-positive extent");
+      if (sizes[d] != 1 && strides[d] != expect)
+        die(fn_, "memref argument is not dense row-major (the reference's memref.cast to the static field type "
+                 "requires the identity layout)");
+      expect *= sizes[d];
+      v.count *= sizes[d];
+      v.box.lb[d] = 0;
+      v.box.ub[d] = sizes[d];
+    }
+    char* first = static_cast<char*>(aligned) + offset * esize;
+    if (neptune_hip_is_device_ptr(first)) {
+      v.dev = first;
+    } else {
+      HostArg h;
+      h.host = first;
+      h.bytes = (size_t)v.count * esize;
+      h.dirty = false;
+      NEPTUNE_HIP_CHECK(hipMalloc(&h.dev, h.bytes));
+      owned_.push_back(h.dev);
+      NEPTUNE_HIP_CHECK(hipMemcpy(h.dev, h.host, h.bytes, hipMemcpyHostToDevice));
+      v.dev = h.dev;
+      v.shadow = (int)host_args_.size();
+      host_args_.push_back(h);
+    }
+    return v;
+  }
+
+  // wrap / unwrap / load: same buffer, new logical box (memref.cast ?->static must be valid)
+  Val alias(const Val& src, const Box& box, const char* op) {
+    if (box.count() != src.count || !box_matches(src, box)) {
+      fprintf(stderr, "[NeptuneRT][HIP] %s: %s: buffer shape does not match the declared field/temp bounds\n", fn_, op);
+      abort();
+    }
+    Val v = src;
+    v.box = box;
+    return v;
+  }
+
+  // ---- results -------------------------------------------------------------------------
+  Val alloc(const Box& box, int esize) {
+    Val v;
+    v.esize = esize;
+    v.box = box;
+    v.count = box.count();
+    size_t bytes = (size_t)v.count * esize;
+    NEPTUNE_HIP_CHECK(hipMalloc(&v.dev, bytes ? bytes : 16));
+    owned_.push_back(v.dev);
+    return v;
+  }
+  void mark_dirty(const Val& v) {
+    if (v.shadow >= 0) host_args_[v.shadow].dirty = true;
+  }
+  // hand a value to the caller: its device buffer leaves this scope's ownership
+  void* release(const Val& v) {
+    for (size_t i = 0; i < owned_.size(); ++i)
+      if (owned_[i] == v.dev) {
+        owned_.erase(owned_.begin() + i);
+        return v.dev;
+      }
+    return nullptr;  // not owned here (an argument or an alias of one)
+  }
+  // flush dirty host shadows; called by the exported wrapper before returning
+  void finish() {
+    NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
+    for (auto& h : host_args_)
+      if (h.dirty) NEPTUNE_HIP_CHECK(hipMemcpy(h.host, h.dev, h.bytes, hipMemcpyDeviceToHost));
+  }
+  // result buffer for the caller: host malloc in host mode (caller free()s it), else the device
+  // buffer itself (caller neptune_rt_free()s it)
+  void* export_result(const Val& v) {
+    NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
+    void* owned = release(v);
+    if (host_mode()) {
+      size_t bytes = (size_t)v.count * v.esize;
+      void* h = malloc(bytes ? bytes : 1);
+      if (!h) die(fn_, "malloc of the result failed");
+      NEPTUNE_HIP_CHECK(hipMemcpy(h, v.dev, bytes, hipMemcpyDeviceToHost));
+      if (owned) NEPTUNE_HIP_CHECK(hipFree(owned));
+      return h;
+    }
+    if (owned) return owned;
+    // returning an alias of an argument that is not ours to give away: hand out a private copy so
+    // the callee-allocates / caller-frees rule still holds
+    void* d = nullptr;
+    size_t bytes = (size_t)v.count * v.esize;
+    NEPTUNE_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 16));
+    NEPTUNE_HIP_CHECK(hipMemcpy(d, v.dev, bytes, hipMemcpyDeviceToDevice));
+    return d;
+  }
+
+ private:
+  static void neptune_hip_init_default() {
+    static bool once = false;
+    if (!once) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) die("init", "no HIP device available");
+      neptune_hip_init(dev);
+      once = true;
+    }
+  }
+  static bool box_matches(const Val& v, const Box& b) {
+    if (v.box.rank != b.rank) return false;
+    return v.box.same_shape(b);
+  }
+  const char* fn_;
+  std::vector<void*> owned_;
+  std::vector<HostArg> host_args_;
+};
+
+inline bool overlaps(const Val& a, const Val& b) {
+  const uintptr_t x = (uintptr_t)a.dev, y = (uintptr_t)b.dev;
+  const uintptr_t na = (uintptr_t)a.count * a.esize, nb = (uintptr_t)b.count * b.esize;
+  return x < y + nb && y < x + na;
+}
+
+inline void fill_geom(neptune_hip_apply_geom_t& g, const Box& out, const Box& bounds, const Val* const* in, int nin) {
+  memset(&g, 0, sizeof(g));
+  g.rank = out.rank;
+  g.num_inputs = nin;
+  for (int d = 0; d < out.rank; ++d) {
+    g.out_lb[d] = out.lb[d];
+    g.out_ub[d] = out.ub[d];
+    g.lb[d] = bounds.lb[d];
+    g.ub[d] = bounds.ub[d];
+    g.region_lb[d] = 0;
+    g.region_ub[d] = out.ub[d] - out.lb[d];
+    for (int k = 0; k < nin; ++k) {
+      g.in_lb[k][d] = in[k]->box.lb[d];
+      g.in_ub[k][d] = in[k]->box.ub[d];
+    }
+  }
+}
+
+// One neptune_ir.apply.  `dest`: a field the single consumer (a whole-buffer store) will copy the
+// result into; when it aliases no input the kernel writes there directly and the copy is elided.
+// `top_radius`: max |offset| of the UNCONDITIONAL accesses (those not nested under scf.if) -- the
+// ones that certainly execute for every in-bounds point and must therefore stay inside their
+// input's box (out of bounds = undefined behaviour in the reference, rejected here).
+template <class Body, class T, int RANK, int NIN, class FP>
+inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const Box& bounds, const Val* const* in,
+                     const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest) {
+  neptune_hip_apply_geom_t g;
+  fill_geom(g, result_box, bounds, in, NIN);
+  int rc = geom_check_radius(&g, top_radius);
+  if (rc == NEPTUNE_HIP_EOOB)
+    die(sc.name(), "neptune_ir.apply reads outside an input's bounds (undefined behaviour in the reference lowering, "
+                   "DataflowLowering.cpp:380-410); refusing to run it");
+  if (rc != NEPTUNE_HIP_OK) die(sc.name(), "malformed neptune_ir.apply geometry");
+  bool direct = dest != nullptr && dest->count == result_box.count();
+  for (int k = 0; direct && k < NIN; ++k) direct = !overlaps(*dest, *in[k]);
+  Val out;
+  if (direct) {
+    out = *dest;
+    out.box = result_box;
+  } else {
+    out = sc.alloc(result_box, (int)sizeof(T));
+  }
+  const void* ptrs[NIN];
+  for (int k = 0; k < NIN; ++k) ptrs[k] = in[k]->dev;
+  rc = launch_apply<Body, T, RANK, NIN, FP>(body, &g, ptrs, out.dev, sc.stream(), nullptr);
+  if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
+  if (direct) sc.mark_dirty(*dest);
+  return out;
+}
+
+// neptune_ir.store (DataflowLowering.cpp:165-220)
+inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds, int dtype) {
+  int rc;
+  if (!bounds) {
+    if (src.dev == dst.dev) {  // the producing apply already wrote into the field
+      sc.mark_dirty(dst);
+      return;
+    }
+    rc = neptune_hip_store_full(dtype, src.dev, dst.dev, src.count, sc.stream());
+  } else {
+    rc = neptune_hip_store_box(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, dst.dev, dst.box.lb, dst.box.ub,
+                               bounds->lb, bounds->ub, sc.stream());
+  }
+  if (rc == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.store bounds leave a buffer");
+  if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.store rejected");
+  sc.mark_dirty(dst);
+}
+
+template <int RANK> struct MemRefOf;
+template <> struct MemRefOf<1> { typedef NeptuneMemRef1D type; };
+template <> struct MemRefOf<2> { typedef NeptuneMemRef2D type; };
+template <> struct MemRefOf<3> { typedef NeptuneMemRef3D type; };
+
+// dense row-major descriptor over `p` (results: offset 0, stride[last] = 1; reference:
+// NeptunePETScRuntime.cpp:881-892 view_x2D)
+template <int RANK>
+inline typename MemRefOf<RANK>::type make_memref(void* p, const Box& box) {
+  typename MemRefOf<RANK>::type r;
+  r.allocated = p;
+  r.aligned = p;
+  r.offset = 0;
+  int64_t st = 1;
+  for (int d = RANK - 1; d >= 0; --d) {
+    r.sizes[d] = box.ub[d] - box.lb[d];
+    r.strides[d] = st;
+    st *= r.sizes[d];
+  }
+  return r;
+}
+
+}  // namespace lowered
+}  // namespace neptune_hip

@@ -1,0 +1,172 @@
+"""Python face of the NeptuneIR -> HIP lowering (libneptune_lowering.so) and loader of the
+modules it produces.
+
+Mirrors the reference's AOT path (python_frontend/neptune/backend.py:15-75): the module text is
+hashed (sha256, first 16 hex digits), the shared object is cached as
+$NEPTUNE_CACHE_DIR/neptune_kernel_<hash>.so (default ~/.neptune/cache) and loaded with ctypes.
+A lowered module exports the reference's calling convention: expanded memref arguments, memref
+struct result (test/smoke_tests/smoke_apply.sh:39-50)."""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _capi
+
+LOWERING_LIB = _capi.PKG_ROOT / "lib" / "libneptune_lowering.so"
+_NP = {"f64": np.float64, "f32": np.float32}
+_lib = None
+
+
+class LoweringError(RuntimeError):
+    pass
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not LOWERING_LIB.exists():
+            raise ImportError(f"{LOWERING_LIB} not found: build it with `make lowering`")
+        lib = C.CDLL(str(LOWERING_LIB))
+        cpp = C.POINTER(C.c_char_p)
+        lib.neptune_lowering_verify.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.neptune_lowering_to_hip.argtypes = [C.c_char_p] + [C.POINTER(C.c_void_p)] * 3
+        lib.neptune_lowering_compile.argtypes = [C.c_char_p] * 4 + [C.POINTER(C.c_void_p)] * 2
+        lib.neptune_lowering_free.argtypes = [C.c_void_p]
+        lib.neptune_lowering_version.restype = C.c_char_p
+        for f in (lib.neptune_lowering_verify, lib.neptune_lowering_to_hip, lib.neptune_lowering_compile):
+            f.restype = C.c_int
+        del cpp
+        _lib = lib
+    return _lib
+
+
+def _take(lib, p: C.c_void_p) -> Optional[str]:
+    if not p.value:
+        return None
+    s = C.string_at(p.value).decode()
+    lib.neptune_lowering_free(p)
+    return s
+
+
+def verify(text: str) -> None:
+    """raise LoweringError with the reference's diagnostic if the module is ill-formed"""
+    lib = _load()
+    diag = C.c_void_p()
+    if lib.neptune_lowering_verify(text.encode(), C.byref(diag)) != 0:
+        raise LoweringError(_take(lib, diag))
+
+
+def to_hip(text: str):
+    """-> (HIP source, report dict)"""
+    lib = _load()
+    src, rep, diag = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    if lib.neptune_lowering_to_hip(text.encode(), C.byref(src), C.byref(rep), C.byref(diag)) != 0:
+        raise LoweringError(_take(lib, diag))
+    return _take(lib, src), json.loads(_take(lib, rep))
+
+
+def cache_dir() -> Path:
+    env = os.environ.get("NEPTUNE_CACHE_DIR")
+    d = Path(env) if env else Path.home() / ".neptune" / "cache"
+    d.mkdir(parents=True, exist_ok=True)
+    return d
+
+
+def module_hash(text: str) -> str:
+    return hashlib.sha256(text.encode("utf-8")).hexdigest()[:16]
+
+
+def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: bool = True) -> "LoweredModule":
+    """lower + hipcc (gfx950) + load.  Compiling needs no GPU; loading needs libneptune_hip.so."""
+    lib = _load()
+    if so_path is None:
+        so_path = cache_dir() / f"neptune_kernel_{module_hash(text)}.so"
+    so_path = Path(so_path)
+    rep_path = so_path.with_suffix(".json")
+    if not (use_cache and so_path.exists() and rep_path.exists()):
+        rep, diag = C.c_void_p(), C.c_void_p()
+        rc = lib.neptune_lowering_compile(text.encode(), str(so_path).encode(), str(_capi.REPO_ROOT).encode(),
+                                          os.environ.get("HIPCC", "").encode() or None, C.byref(rep), C.byref(diag))
+        if rc != 0:
+            raise LoweringError(_take(lib, diag))
+        rep_path.write_text(_take(lib, rep))
+    return LoweredModule(so_path, json.loads(rep_path.read_text()))
+
+
+class LoweredModule:
+    """a compiled module: call exported symbols with numpy arrays (host buffers: staged through the
+    device, result comes back in malloc'ed host memory) or with DeviceField / torch CUDA tensors
+    (device buffers: used in place, result stays on the device)"""
+
+    def __init__(self, so_path: Path, report: dict):
+        _capi.load()  # libneptune_hip.so first (RTLD_GLOBAL): the module links against it
+        self.path = Path(so_path)
+        self.report = report
+        self.lib = C.CDLL(str(so_path))
+        self.signatures: Dict[str, dict] = {s["name"]: s for s in report["signatures"]}
+        for name, sig in self.signatures.items():
+            fn = getattr(self.lib, name)
+            argtypes: List = []
+            for a in sig["args"]:
+                argtypes += [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int64] * (2 * a["rank"])
+            fn.argtypes = argtypes
+            fn.restype = _capi.MEMREF[sig["result"]["rank"]] if sig["result"] else None
+
+    @property
+    def symbols(self) -> List[str]:
+        return list(self.signatures)
+
+    def call(self, name: str, *args):
+        sig = self.signatures[name]
+        if len(args) != len(sig["args"]):
+            raise TypeError(f"@{name} takes {len(sig['args'])} arguments")
+        flat: List = []
+        keep = []
+        device_mode = None
+        for a, spec in zip(args, sig["args"]):
+            if isinstance(a, np.ndarray):
+                if a.dtype != _NP[spec["elem"]] or a.ndim != spec["rank"] or not a.flags["C_CONTIGUOUS"]:
+                    raise TypeError(f"@{name}: argument must be a C-contiguous {spec['elem']} array of rank {spec['rank']}")
+                ptr, shape, is_dev = a.ctypes.data, a.shape, False
+            else:
+                t = getattr(a, "tensor", a)  # DeviceField or torch tensor
+                if not t.is_cuda or not t.is_contiguous() or t.dim() != spec["rank"]:
+                    raise TypeError(f"@{name}: device argument must be a contiguous CUDA tensor of rank {spec['rank']}")
+                ptr, shape, is_dev = t.data_ptr(), tuple(t.shape), True
+            if device_mode is None:
+                device_mode = is_dev
+            keep.append(a)
+            strides = [1] * len(shape)
+            for d in range(len(shape) - 2, -1, -1):
+                strides[d] = strides[d + 1] * shape[d + 1]
+            flat += [ptr, ptr, 0] + list(shape) + strides
+        fn = getattr(self.lib, name)
+        ret = fn(*flat)
+        if not sig["result"]:
+            return None
+        shape = tuple(ret.sizes)
+        for a in keep:  # result aliases an argument (e.g. @entry returns its destination field)
+            p = a.ctypes.data if isinstance(a, np.ndarray) else getattr(a, "tensor", a).data_ptr()
+            if ret.aligned == p:
+                return a
+        hip = _capi.load()
+        dt = _NP[sig["result"]["elem"]]
+        count = int(np.prod(shape))
+        if hip.neptune_hip_is_device_ptr(ret.aligned):
+            import torch
+            out = torch.empty(shape, dtype={np.float64: torch.float64, np.float32: torch.float32}[dt], device="cuda")
+            hip.neptune_hip_memcpy_d2d(out.data_ptr(), ret.aligned, count * dt().itemsize, None)
+            hip.neptune_hip_device_sync()
+            hip.neptune_rt_free(ret.allocated)   # callee allocated, caller frees
+            return out
+        buf = (C.c_char * (count * dt().itemsize)).from_address(ret.aligned)
+        out = np.frombuffer(buf, dtype=dt).reshape(shape).copy()
+        hip.neptune_rt_free(ret.allocated)       # host result: free()
+        return out
