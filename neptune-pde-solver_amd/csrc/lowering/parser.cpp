@@ -542,6 +542,16 @@ struct Parser {
         if (!expect("{")) return false;
         while (ok() && !accept("}")) {
           if (peek().kind == Tk::Eof) { diag.fail(peek().line, "unexpected end of input inside module"); return false; }
+          // stray module-level solver ops (the reference's Python builder can leave e.g. an
+          // assemble_matrix there): nothing to lower, skip them
+          const bool stray_result = is_value();
+          const bool stray_op = peek().kind == Tk::Id && peek().text.compare(0, 11, "neptune_ir.") == 0 &&
+                                peek().text != "neptune_ir.linear_opdef" && peek().text != "neptune_ir.nonlinear_opdef";
+          if (stray_result || stray_op) {
+            next();
+            skip_opaque();
+            continue;
+          }
           if (!parse_function(m)) return false;
         }
       } else if (k.text == "func.func" || k.text == "neptune_ir.linear_opdef" || k.text == "neptune_ir.nonlinear_opdef") {

@@ -378,6 +378,13 @@ class Parser:
                     self.parse_attr_dict()
                 self.expect("{")
                 while not self.accept("}"):
+                    t2 = self.peek()
+                    stray = t2.text.startswith("%") or (t2.text.startswith("neptune_ir.") and
+                                                         t2.text not in ("neptune_ir.linear_opdef", "neptune_ir.nonlinear_opdef"))
+                    if stray:   # module-level solver op left by the Python builder: nothing to evaluate
+                        self.next()
+                        self._skip_opaque_op()
+                        continue
                     f = self.parse_function()
                     funcs[f.name] = f
             elif t.text in ("func.func", "neptune_ir.linear_opdef", "neptune_ir.nonlinear_opdef"):

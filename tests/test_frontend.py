@@ -1,0 +1,136 @@
+"""Python frontend mirror (`neptune` package): same API surface as the reference's
+python_frontend/neptune; the IR it builds is valid for BOTH independent front ends (the oracle's
+Python parser and the product's C++ parser) and means what the DSL says (checked with the oracle)."""
+import numpy as np
+import pytest
+
+import helpers
+from helpers import bits_equal, oracle
+
+import neptune as nep
+from neptune import _neptune_mlir
+from neptune_hip import lowering
+
+
+@pytest.fixture(autouse=True)
+def fresh_module():
+    nep.reset()
+    yield
+    nep.reset()
+
+
+def test_public_api_matches_the_reference_package():
+    # python_frontend/neptune/__init__.py:32-44
+    for name in ["Context", "get_compiler", "Expr", "apply", "stencil", "linear_op_def", "assemble_matrix",
+                 "solve_linear", "jit_compile", "jit_class"]:
+        assert hasattr(nep, name), name
+    assert nep.stencil is nep.apply
+    # python_frontend/bindings/NeptuneModule.cpp:11-35: the 16 Compiler methods
+    for m in ["dump", "create_wrap", "create_access", "create_arith_add", "create_arith_sub", "create_arith_mul",
+              "create_constant", "create_apply", "create_linear_opdef", "create_assemble_matrix", "create_solve_linear",
+              "start_function", "end_function", "get_function_arg", "create_return", "compile_to_object_file"]:
+        assert callable(getattr(_neptune_mlir.Compiler, m)), m
+    assert "Value" in repr(_neptune_mlir.Value(None, _neptune_mlir._Type("none")))
+    assert nep.Context().dump().startswith("module {")
+
+
+def test_reference_user_program_builds_the_expected_ir():
+    """test/python_tests/test_user.py of the reference, same source text"""
+    @nep.linear_op_def(bounds=([0], [100]), location="cell")
+    def laplacian_1d(u):
+        return u[0] * 2.0 - u[-1] - u[1]
+
+    assert laplacian_1d == "laplacian_1d"           # the decorator returns the symbol name (dsl.py:58)
+    H = nep.assemble_matrix(laplacian_1d)
+    assert isinstance(H, nep.Expr)
+    text = nep.get_compiler().dump()
+    assert "neptune_ir.linear_opdef @laplacian_1d" in text and "neptune_ir.assemble_matrix @laplacian_1d : memref<?x?xf64>" in text
+    # region signature as the reference verifier wants it: index args first, then the temps
+    assert "^bb0(%i" in text and ": index, %in" in text
+    _, report = lowering.to_hip(text)               # C++ front end accepts it; the opdef is lowered
+    assert report["lowered"] == ["laplacian_1d"]
+    m = oracle.Module.parse(text)                   # ... and so does the oracle's parser
+    # over the FULL box the +-1 accesses leave the field: undefined behaviour in the reference
+    with pytest.raises(oracle.OutOfBounds):
+        m.call("laplacian_1d", np.arange(100, dtype=np.float64))
+
+
+def _build_heat2d(n0, n1, alpha=0.125):
+    box = ([0, 0], [n0, n1])
+
+    @nep.linear_op_def(bounds=box, location="cell", apply_bounds=([1, 1], [n0 - 1, n1 - 1]))
+    def lap2d(u):
+        return (u[-1, 0] + u[1, 0] + u[0, -1] + u[0, 1] - 4.0 * u[0, 0]) * alpha
+
+    c = nep.get_compiler()
+    c.start_function("entry", [("memref", 2), ("memref", 2)])
+    out, src = nep.Expr(c.get_function_arg(0)), nep.Expr(c.get_function_arg(1))
+    fout, fin = nep.wrap(out, box), nep.wrap(src, box)
+    y = nep.apply_linear(lap2d, nep.load(fin))
+    nep.store(y, fout)
+    c.create_return(nep.unwrap(fout)._handle)
+    c.end_function()
+    return c.dump()
+
+
+def test_dsl_built_module_means_what_it_says():
+    n0, n1 = 9, 12
+    text = _build_heat2d(n0, n1)
+    lowering.verify(text)
+    src, report = lowering.to_hip(text)
+    assert report["lowered"] == ["lap2d", "entry"] and report["applies"][0]["kernel"] == "march"
+    u = helpers.hash_field((n0, n1), np.float64, seed=5)
+    out = np.zeros_like(u)
+    oracle.Module.parse(text).call("entry", out, u)
+    want = u.copy()
+    # Python evaluates left to right exactly as the tracer emitted the ops
+    want[1:-1, 1:-1] = ((((u[:-2, 1:-1] + u[2:, 1:-1]) + u[1:-1, :-2]) + u[1:-1, 2:]) - 4.0 * u[1:-1, 1:-1]) * 0.125
+    assert bits_equal(out, want)
+
+
+def test_apply_decorator_and_reverse_operators():
+    c = nep.get_compiler()
+    c.start_function("f", [("temp", [0], [8])])
+    u = nep.Expr(c.get_function_arg(0))
+
+    @nep.apply(inputs=[u], bounds=([1], [7]))
+    def r(a):
+        return 2.0 * a[0] - (a[-1] + a[1]) / 4.0
+
+    assert isinstance(r, nep.Expr)
+    c.create_return(r._handle)
+    c.end_function()
+    text = c.dump()
+    x = np.arange(8, dtype=np.float64) ** 2
+    got = oracle.Module.parse(text).call("f", x)
+    want = x.copy()
+    want[1:7] = 2.0 * x[1:7] - (x[0:6] + x[2:8]) / 4.0
+    assert bits_equal(got, want)
+    lowering.verify(text)
+    with pytest.raises(TypeError):
+        u + "nope"
+
+
+def test_builder_errors():
+    c = nep.get_compiler()
+    with pytest.raises(RuntimeError, match="Not inside a function"):
+        c.get_function_arg(0)
+    c.start_function("g", [("temp", [0, 0], [4, 4])])
+    t = c.get_function_arg(0)
+    with pytest.raises(ValueError):
+        c.create_access(t, [0])                   # rank mismatch
+    with pytest.raises(TypeError):
+        c.create_apply([t], [1, 1], [3, 3], lambda a: a[0])   # body must yield a scalar, not a temp
+    with pytest.raises(RuntimeError):
+        c.start_function("h", [])
+
+
+def test_compile_to_object_file_and_jit_cache(tmp_path, monkeypatch, built_libs):
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path / "cache"))
+    _build_heat2d(16, 128)
+    obj = tmp_path / "heat.o"
+    nep.get_compiler().compile_to_object_file(str(obj))
+    assert obj.stat().st_size > 1000
+    mod = nep.jit_compile(nep.get_compiler())      # lowers + hipcc + dlopen (no GPU needed to load)
+    assert mod.path.parent == tmp_path / "cache" and mod.path.name.startswith("neptune_kernel_")
+    assert set(mod.symbols) == {"lap2d", "entry"}

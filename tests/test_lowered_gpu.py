@@ -175,3 +175,41 @@ print("NOT REACHED")
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True)
     assert p.returncode != 0 and "NOT REACHED" not in p.stdout
     assert "[NeptuneRT][HIP] kat_lap: neptune_ir.apply reads outside an input's bounds" in p.stderr
+
+
+def test_python_dsl_jit_class_end_to_end(env):
+    """reference-style user program: operator defined with @linear_op_def, solver class traced by
+    @jit_class, called with NumPy arrays (host path) and CUDA tensors (device path)"""
+    lowering, torch = env
+    import neptune as nep
+    n0, n1 = 40, 256
+    box = ([0, 0], [n0, n1])
+
+    @nep.jit_class
+    class Heat2D:
+        def __init__(self, alpha):
+            self.alpha = alpha
+
+        def define_operators(self):
+            alpha = self.alpha
+
+            @nep.linear_op_def(bounds=box, location="cell", apply_bounds=([1, 1], [n0 - 1, n1 - 1]))
+            def lap2d(u):
+                return (u[-1, 0] + u[1, 0] + u[0, -1] + u[0, 1] - 4.0 * u[0, 0]) * alpha
+
+        def step(self, out, u):
+            fout, fin = nep.wrap(out, box), nep.wrap(u, box)
+            y = nep.apply_linear("lap2d", nep.load(fin))
+            nep.store(y, fout)
+            return nep.unwrap(fout)
+
+    solver = Heat2D(0.125)
+    u = helpers.hash_field((n0, n1), np.float64, seed=77)
+    out = np.zeros_like(u)
+    res = solver.step(out, u)
+    want = u.copy()
+    want[1:-1, 1:-1] = ((((u[:-2, 1:-1] + u[2:, 1:-1]) + u[1:-1, :-2]) + u[1:-1, 2:]) - 4.0 * u[1:-1, 1:-1]) * 0.125
+    assert res is out and bits_equal(out, want), mismatch_report(out, want)
+    d_out = torch.zeros((n0, n1), dtype=torch.float64, device="cuda")
+    solver.step(d_out, torch.from_numpy(u).cuda())      # second call: no re-trace, device path
+    assert bits_equal(d_out.cpu().numpy(), want)
