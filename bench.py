@@ -74,8 +74,9 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
     for n in shape[1:]:
         plane_cells *= n
     if sample_planes <= 0:
-        # ~5e8 cells keeps the whole CPU leg (fill + scalar 3-pass run + 3 fused runs) in the 10-30 s band
-        sample_planes = max(3, min(shape[0], int(5.0e8 // plane_cells)))
+        # up to ~1.1e9 cells (the whole 1024^3 field: 3 x 8 GiB of host memory) keeps the CPU leg
+        # (fill + one scalar 3-pass run + 3 fused runs) around 10 s on the GPU node's host
+        sample_planes = max(3, min(shape[0], int(1.1e9 // plane_cells)))
     sshape = (sample_planes,) + tuple(shape[1:])
     count = sample_planes * plane_cells
     fill = lib.ref_fill_hash_f64 if elem_bytes == 8 else lib.ref_fill_hash_f32

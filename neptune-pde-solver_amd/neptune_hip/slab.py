@@ -127,11 +127,38 @@ def halo_ops(slab: Slab, t: torch.Tensor, group=None) -> List[dist.P2POp]:
     return ops
 
 
+class _HostStaged:
+    """work handle of the rehearsal path below: wait() finishes the exchange and copies back"""
+
+    def __init__(self, works, copies):
+        self.works, self.copies = works, copies
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, src in self.copies:
+            dst.copy_(src)
+
+
 def exchange_halos(slab: Slab, t: torch.Tensor, group=None) -> list:
-    """start the exchange; returns the work handles (call .wait() on each)"""
+    """start the exchange; returns the work handles (call .wait() on each).
+
+    Production: RCCL send/recv straight between device buffers (backend "nccl").  If the process
+    group is gloo and the buffer lives on a GPU (multi-rank rehearsal on a one-GPU box, where RCCL
+    cannot pair two ranks on one device) the planes are staged through host memory instead: same
+    geometry, same ordering, different transport."""
     ops = halo_ops(slab, t, group)
     if not ops:
         return []
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        staged, copies = [], []
+        torch.cuda.current_stream().synchronize()
+        for op in ops:
+            host = op.tensor.detach().cpu() if op.op is dist.isend else torch.empty_like(op.tensor, device="cpu")
+            staged.append(dist.P2POp(op.op, host, op.peer, group))
+            if op.op is dist.irecv:
+                copies.append((op.tensor, host))
+        return [_HostStaged(dist.batch_isend_irecv(staged), copies)]
     return dist.batch_isend_irecv(ops)
 
 

@@ -213,3 +213,22 @@ def test_python_dsl_jit_class_end_to_end(env):
     d_out = torch.zeros((n0, n1), dtype=torch.float64, device="cuda")
     solver.step(d_out, torch.from_numpy(u).cuda())      # second call: no re-trace, device path
     assert bits_equal(d_out.cpu().numpy(), want)
+
+
+def test_c_caller_in_the_style_of_the_petsc_matmult_thunk(env, tmp_path):
+    """a plain C program looks the lowered operator up with dlsym(RTLD_DEFAULT), calls it with a host
+    array and free()s the result -- the three things LinSolverCtx::MatMultThunk does
+    (reference lib/Runtime/PETSc/NeptunePETScRuntime.cpp:182-230)"""
+    lowering, _ = env
+    doc = helpers.load_kats()
+    mod = lowering.compile_module((helpers.REPO / doc["ir"]).read_text())
+    exe = tmp_path / "thunk"
+    subprocess.run(["gcc", "-O1", str(helpers.REPO / "tests/thunk_abi/matmult_thunk.c"), "-ldl", "-o", str(exe)], check=True)
+    from neptune_hip import _capi
+    env_vars = dict(__import__("os").environ, LD_LIBRARY_PATH=str(_capi.LIB_PATH.parent))
+    for sym, n, name in (("kat_lap", 16, "KAT-1 ac_lap, driver input"), ("kat_bs", 32, "KAT-3 Black-Scholes operator")):
+        p = subprocess.run([str(exe), str(mod.path), sym, str(n)], capture_output=True, text=True, env=env_vars)
+        assert p.returncode == 0, p.stderr
+        got = np.array([float.fromhex(t) for t in p.stdout.split()])
+        want = _vec(next(k for k in doc["kats"] if k["name"] == name)["expected"])
+        assert bits_equal(got, want), name
