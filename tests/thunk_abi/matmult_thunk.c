@@ -7,6 +7,7 @@
  * usage: matmult_thunk <module.so> <symbol> <n>   (input x[i] = i+1, the smoke drivers' convention)
  * prints y[i] as C99 hex floats, one per line.
  */
+#define _GNU_SOURCE
 #include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
