@@ -51,6 +51,11 @@ def parse_args():
     ap.add_argument("--variant", type=int, default=-1, help="march tile variant (-1 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="march planes per workgroup (0 = auto)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos before the interior (debug)")
+    ap.add_argument("--emulate-rank", default="",
+                    help="diagnostic, single process: 'R/W' runs the compute launches rank R of W would issue "
+                         "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
+    ap.add_argument("--fixed-input", action="store_true",
+                    help="diagnostic: every step reads field 0 and writes field 1 (no ping-pong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-planes", type=int, default=0, help="dim-0 extent of the CPU sample (0 = auto)")
     ap.add_argument("--hbm-traffic-bytes", type=float, default=None,
@@ -148,9 +153,15 @@ def main():
     gbox = ([0] * rank_nd, list(gshape))
     gbounds = ([1] * rank_nd, [n - 1 for n in gshape])
     kernel = {"auto": _capi.KERNEL_AUTO, "direct": _capi.KERNEL_DIRECT, "march": _capi.KERNEL_MARCH}[args.kernel]
-    cfg = nh_apply.make_cfg(kernel, max(args.variant, 0), args.chunk)
+    cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
 
-    sl = slab_mod.decompose(gbox, 1, rank, world)
+    emu = None
+    if args.emulate_rank:
+        if world != 1:
+            sys.exit("--emulate-rank is a single-process diagnostic")
+        er, ew = (int(x) for x in args.emulate_rank.split("/"))
+        emu = (er, ew)
+    sl = slab_mod.decompose(gbox, 1, rank, world) if emu is None else slab_mod.decompose(gbox, 1, emu[0], emu[1])
     # two device-resident local fields (owned planes + ghost planes), ping-pong
     plane_cells = 1
     for n in gshape[1:]:
@@ -161,14 +172,33 @@ def main():
     bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
     bufs[1].tensor.zero_()
     op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap)
+    sharded = op
     stream_ptr = fields.current_stream_ptr()
+    if emu is not None:
+        # same launches as the real rank, ghosts simply left as initialised
+        def emu_step(fin, fout, _op=op):
+            rec = _op._records(fin, fout)
+            if rec["interior"] is not None:
+                _op._launch(rec, rec["interior"], fout, stream_ptr)
+            for e in rec["edges"]:
+                _op._launch(rec, e, fout, stream_ptr)
+        op = emu_step
+    elif world > 1:
+        # RCCL builds its point-to-point channels on first use (seconds): do that outside every
+        # timed or counted step, whatever --warmup says
+        for w in slab_mod.exchange_halos(sl, bufs[0].tensor):
+            w.wait()
+        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
             dist.barrier()
 
     def step(s):
-        op(bufs[s % 2], bufs[(s + 1) % 2])
+        if args.fixed_input:
+            op(bufs[0], bufs[1])
+        else:
+            op(bufs[s % 2], bufs[(s + 1) % 2])
 
     for s in range(args.warmup):
         step(s)
@@ -219,8 +249,12 @@ def main():
             alg_bytes = 2.0 * own_cells * esize
             kern_ms = ev_ms / args.steps  # per step on this rank's compute stream (interior + edges + waits)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        plan = nh_apply.plan_builtin(body, [bufs[0]], bufs[1], op.bounds, region=op._own_region(), cfg=cfg)
-        vname = lib.neptune_hip_march_variant_name(rank_nd, cfg.variant).decode() if plan == _capi.KERNEL_MARCH else ""
+        plan = nh_apply.plan_builtin(body, [bufs[0]], bufs[1], sharded.bounds, region=sharded._own_region(), cfg=cfg)
+        auto_variant = 1 if (rank_nd == 3 and points == 27) else 0      # apply_launch.hpp: box stencils take tile 1
+        vidx = cfg.variant if cfg.variant >= 0 else auto_variant
+        if world > 1 and rank_nd == 2 and vidx == 0:
+            vidx = 1                                                   # row-restricted launches use the march form
+        vname = lib.neptune_hip_march_variant_name(rank_nd, vidx).decode() if plan == _capi.KERNEL_MARCH else ""
         # HBM traffic cannot be counted live (PMC needs rocprofv3): report the per-launch bytes of
         # the matching kernel/shape from the committed separate-pass profile, or null
         traffic, traffic_src = args.hbm_traffic_bytes, "command line" if args.hbm_traffic_bytes else None
@@ -249,6 +283,7 @@ def main():
                             f"interior bounds, copy-through boundary, ping-pong fields",
                 "fixture": {"lap3d7_f64": "apply-3d-7pt.mlir", "lap2d5_f64": "apply-2d-5pt.mlir",
                             "lap3d27_f32": "apply-3d-27pt.mlir"}[body_name],
+                "emulated_rank": args.emulate_rank or None,
                 "decomposition": f"dim-0 slabs x{world}, 1 halo plane/neighbour over RCCL"
                                  + ("" if args.no_overlap else ", overlapped with interior") if world > 1 else "single GPU",
                 "kernel": lib.neptune_hip_kernel_name(plan).decode(),

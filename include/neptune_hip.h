@@ -117,10 +117,11 @@ typedef struct {
   int64_t region_lb[NEPTUNE_HIP_MAX_RANK], region_ub[NEPTUNE_HIP_MAX_RANK];
 } neptune_hip_apply_geom_t;
 
-/* launch tuning; zero-initialised = defaults */
+/* launch tuning; pass NULL (or variant = -1, kernel = chunk = 0) for the defaults */
 typedef struct {
   int32_t kernel;   /* NEPTUNE_HIP_KERNEL_* */
-  int32_t variant;  /* march tile variant, 0 = default; see neptune_hip_march_variant_name */
+  int32_t variant;  /* march tile variant; negative = automatic (default tile for the stencil shape);
+                       see neptune_hip_march_variant_name */
   int32_t chunk;    /* march: planes per workgroup along dim 0, 0 = auto */
   int32_t flags;    /* reserved, must be 0 */
 } neptune_hip_launch_cfg_t;

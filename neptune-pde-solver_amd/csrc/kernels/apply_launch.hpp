@@ -96,63 +96,60 @@ struct MarchVariant {
   int RJ, WJ, WK;
   bool dpp, nt;
   int PF;
-  bool ntl, ldsj;
+  bool ntl, ldsj, jk;
   const char* name;
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, name)
-// Variant 0 is the default (best measured on MI355X for the 1024^3 fp64 7-point apply and
-// the 512^3 fp32 27-point apply, sweep of round 1: profiles/r01_sweep.txt); the others stay
-// compiled into the runtime library for tools/sweep.py and for the parity tests, which run
-// every one of them.
-#define NEPTUNE_MARCH3_DEFAULT(X) X(0, 4, 4, 2, true, true, 2, false, true, "rj4_wj4_wk2_pf2_lds")
-#define NEPTUNE_MARCH2_DEFAULT(X) X(0, 1, 1, 4, true, true, 4, false, false, "wk4_pf4")
+// The first two variants of each rank are the defaults and are compiled into every lowered
+// module; the others stay in the runtime library for tools/sweep.py and for the parity tests,
+// which run every one of them.  Measured on MI355X (profiles/r01_sweep_report.txt):
+//   rank 3, star  : 0  rj4_wj4_wk2_pf2_lds   (1024^3 fp64 7-point: 6.1 TB/s)
+//   rank 3, box   : 1  rj4_wj8_wk1_pf2_lds   (512^3 fp32 27-point: 5.6 TB/s)
+//   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s), and
+//                   1  wk4_pf4, the march form, for launches restricted to a row range
+// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name)
+#define NEPTUNE_MARCH3_DEFAULT(X)                                            \
+  X(0, 4, 4, 2, true, true, 2, false, true, false, "rj4_wj4_wk2_pf2_lds")    \
+  X(1, 4, 8, 1, true, true, 2, false, true, false, "rj4_wj8_wk1_pf2_lds")
+#define NEPTUNE_MARCH2_DEFAULT(X)                                            \
+  X(0, 4, 8, 1, true, true, 1, false, true, true, "tile_rj4_wj8_wk1")        \
+  X(1, 1, 1, 4, true, true, 4, false, false, false, "wk4_pf4")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(1, 4, 4, 1, false, false, 1, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(2, 4, 4, 1, true, true, 2, false, false, "rj4_wj4_wk1_pf2")        \
-  X(3, 2, 4, 1, true, true, 2, false, false, "rj2_wj4_wk1_pf2")        \
-  X(4, 8, 2, 1, true, true, 1, false, false, "rj8_wj2_wk1_pf1")        \
-  X(5, 4, 8, 1, true, true, 2, false, false, "rj4_wj8_wk1_pf2")        \
-  X(6, 4, 4, 1, true, true, 3, false, false, "rj4_wj4_wk1_pf3")        \
-  X(7, 2, 2, 2, true, true, 3, false, false, "rj2_wj2_wk2_pf3")        \
-  X(8, 4, 4, 1, true, true, 1, false, true, "rj4_wj4_wk1_pf1_lds")     \
-  X(9, 4, 4, 1, true, true, 2, false, true, "rj4_wj4_wk1_pf2_lds")     \
-  X(10, 4, 8, 1, true, true, 2, false, true, "rj4_wj8_wk1_pf2_lds")    \
-  X(11, 2, 8, 1, true, true, 2, false, true, "rj2_wj8_wk1_pf2_lds")    \
-  X(12, 2, 8, 1, true, true, 4, false, true, "rj2_wj8_wk1_pf4_lds")    \
-  X(13, 4, 4, 1, true, true, 3, false, true, "rj4_wj4_wk1_pf3_lds")    \
-  X(14, 2, 4, 1, true, true, 3, false, true, "rj2_wj4_wk1_pf3_lds")    \
-  X(15, 4, 4, 1, true, true, 1, false, false, "rj4_wj4_wk1_pf1")       \
-  X(16, 2, 16, 1, true, true, 3, false, true, "rj2_wj16_wk1_pf3_lds")  \
-  X(17, 1, 16, 1, true, true, 4, false, true, "rj1_wj16_wk1_pf4_lds")  \
-  X(18, 8, 4, 1, true, true, 1, false, true, "rj8_wj4_wk1_pf1_lds")    \
-  X(19, 4, 8, 1, true, true, 3, false, true, "rj4_wj8_wk1_pf3_lds")    \
-  X(20, 4, 4, 2, true, true, 3, false, true, "rj4_wj4_wk2_pf3_lds")    \
-  X(21, 8, 4, 2, true, true, 1, false, true, "rj8_wj4_wk2_pf1_lds")    \
-  X(22, 4, 2, 4, true, true, 2, false, true, "rj4_wj2_wk4_pf2_lds")    \
-  X(23, 4, 4, 2, true, true, 1, false, true, "rj4_wj4_wk2_pf1_lds")    \
-  X(24, 4, 4, 2, true, true, 2, true, true, "rj4_wj4_wk2_pf2_ntl_lds")
-// rank 2: J has extent 1, a workgroup is WK waves side by side
+  X(2, 4, 4, 1, false, false, 1, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(3, 4, 4, 1, true, true, 2, false, false, false, "rj4_wj4_wk1_pf2")        \
+  X(4, 2, 4, 1, true, true, 2, false, false, false, "rj2_wj4_wk1_pf2")        \
+  X(5, 8, 2, 1, true, true, 1, false, false, false, "rj8_wj2_wk1_pf1")        \
+  X(6, 4, 4, 1, true, true, 1, false, false, false, "rj4_wj4_wk1_pf1")        \
+  X(7, 4, 4, 1, true, true, 2, false, true, false, "rj4_wj4_wk1_pf2_lds")     \
+  X(8, 2, 8, 1, true, true, 4, false, true, false, "rj2_wj8_wk1_pf4_lds")     \
+  X(9, 8, 4, 1, true, true, 1, false, true, false, "rj8_wj4_wk1_pf1_lds")     \
+  X(10, 8, 4, 2, true, true, 1, false, true, false, "rj8_wj4_wk2_pf1_lds")    \
+  X(11, 4, 4, 2, true, true, 3, false, true, false, "rj4_wj4_wk2_pf3_lds")    \
+  X(12, 4, 2, 4, true, true, 2, false, true, false, "rj4_wj2_wk4_pf2_lds")    \
+  X(13, 2, 16, 1, true, true, 3, false, true, false, "rj2_wj16_wk1_pf3_lds")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
-  X(1, 1, 1, 4, false, false, 1, false, false, "wk4_pf1_shfl_plainst") \
-  X(2, 1, 1, 4, true, true, 2, false, false, "wk4_pf2")  \
-  X(3, 1, 1, 4, true, true, 1, false, false, "wk4_pf1")  \
-  X(4, 1, 1, 1, true, true, 2, false, false, "wk1_pf2")  \
-  X(5, 1, 1, 1, true, true, 4, false, false, "wk1_pf4")  \
-  X(6, 1, 1, 1, true, true, 8, false, false, "wk1_pf8")  \
-  X(7, 1, 1, 2, true, true, 4, false, false, "wk2_pf4")  \
-  X(8, 1, 1, 4, true, true, 4, true, false, "wk4_pf4_ntl") \
-  X(9, 1, 1, 4, true, true, 8, false, false, "wk4_pf8")  \
-  X(10, 1, 1, 8, true, true, 4, false, false, "wk8_pf4")
+  X(2, 1, 1, 4, false, false, 1, false, false, false, "wk4_pf1_shfl_plainst") \
+  X(3, 1, 1, 4, true, true, 2, false, false, false, "wk4_pf2")  \
+  X(4, 1, 1, 1, true, true, 4, false, false, false, "wk1_pf4")  \
+  X(5, 1, 1, 4, true, true, 8, false, false, false, "wk4_pf8")  \
+  X(6, 4, 16, 1, true, true, 1, false, true, true, "tile_rj4_wj16_wk1")  \
+  X(7, 8, 8, 1, true, true, 1, false, true, true, "tile_rj8_wj8_wk1")    \
+  X(8, 2, 16, 1, true, true, 1, false, true, true, "tile_rj2_wj16_wk1")  \
+  X(9, 4, 4, 2, true, true, 1, false, true, true, "tile_rj4_wj4_wk2")    \
+  X(10, 4, 8, 2, true, true, 1, false, true, true, "tile_rj4_wj8_wk2")   \
+  X(11, 8, 4, 1, true, true, 1, false, true, true, "tile_rj8_wj4_wk1")   \
+  X(12, 4, 4, 1, true, true, 1, false, true, true, "tile_rj4_wj4_wk1")   \
+  X(13, 4, 8, 1, false, false, 1, false, true, true, "tile_rj4_wj8_wk1_shfl_plainst")
 #else
 #define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
 #define NEPTUNE_MARCH2_VARIANTS(X) NEPTUNE_MARCH2_DEFAULT(X)
 #endif
 
-#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name},
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name},
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
@@ -176,11 +173,12 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
   int64_t chunk = chunk_req;
   if (chunk <= 0) {
-    // Measured on MI355X (profiles/r01_sweep.txt): 64 planes per workgroup for 3-D tiles and 32
-    // rows for 2-D strips balance the 2*R0 planes re-read per chunk against having several
-    // rounds of workgroups per CU; shrink only when the grid would not fill the chip.
-    chunk = RANK == 3 ? 64 : 32;
-    const int64_t min_blocks = 2 * 256;  // two workgroups per CU
+    // Measured on MI355X (profiles/r01_sweep_report.txt, profiles/r01_slab_chunks.txt): long chunks
+    // win -- every chunk re-reads 2*R0 planes and restarts the prefetch pipeline -- as long as
+    // there is about one workgroup per CU; 128 planes for 3-D tiles (one chunk per 8-GPU slab of
+    // the 1024^3 problem), 32 rows for the 2-D march form.
+    chunk = RANK == 3 ? 128 : 32;
+    const int64_t min_blocks = 256;
     while (chunk > 8 && ((planes + chunk - 1) / chunk) * tilesJK < min_blocks) chunk /= 2;
   }
   if (chunk > planes) chunk = planes;
@@ -199,10 +197,10 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
 template <class Body, class T, int RANK, int NIN, class FP>
 inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
                          hipStream_t stream) {
-#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, name)                                          \
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name)                                      \
   case idx:                                                                                                     \
-    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ>>(P, body, planes, chunk, \
-                                                                                           stream);              \
+    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2>>(     \
+        P, body, planes, chunk, stream);                                                                        \
     break;
   if constexpr (RANK == 3) {
     switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }
@@ -266,15 +264,30 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
     MarchParams<T, NIN> P{};
     for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
     P.out = static_cast<T*>(out);
+    // variant < 0 (or no cfg): automatic -- box stencils of rank 3 take their own default tile
+    int variant = cfg ? cfg->variant : -1;
+    if (variant < 0 || variant >= march_variant_count(RANK)) variant = (RANK == 3 && FP::BOX) ? 1 : 0;
+    // rank-2 tile form: (d0,d1) -> (J,K), one plane.  It cannot restrict rows (the march kernel's
+    // region is a plane range), so a row-restricted launch takes the default march form.
+    bool jk = RANK == 2 && march_variant(RANK, variant)->jk;
+    const int64_t field_bytes = (g->out_ub[0] - g->out_lb[0]) * (RANK > 1 ? g->out_ub[1] - g->out_lb[1] : 1) * (int64_t)sizeof(T);
+    if (jk && (g->region_lb[0] != 0 || g->region_ub[0] != g->out_ub[0] - g->out_lb[0] || field_bytes >= 0x7fffffffLL)) {
+      jk = false;
+      variant = 1;  // the march form
+    }
+    auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
+      if (jk) { dst[0] = fill; dst[1] = src[0]; dst[2] = src[1]; }
+      else to_axes<RANK>(src, dst, fill);
+    };
     int64_t shape[3], plb[3], pub[3], n[3], a_lb[3], a_ub[3], rlb[3], rub[3];
     for (int d = 0; d < RANK; ++d) {
       shape[d] = g->out_ub[d] - g->out_lb[d];
       plb[d] = g->lb[d] - g->out_lb[d];  // result-physical bounds
       pub[d] = g->ub[d] - g->out_lb[d];
     }
-    to_axes<RANK>(shape, n, 1);
-    to_axes<RANK>(plb, a_lb, 0);
-    to_axes<RANK>(pub, a_ub, 1);
+    axes(shape, n, 1);
+    axes(plb, a_lb, 0);
+    axes(pub, a_ub, 1);
     P.N0 = (int32_t)n[0]; P.N1 = (int32_t)n[1]; P.N2 = (int32_t)n[2];
     for (int a = 0; a < 3; ++a) {
       // clamp into [0, extent] so the int32 narrowing is exact (empty bounds stay empty)
@@ -283,12 +296,13 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
       P.plb[a] = (int32_t)lo;
       P.pub[a] = (int32_t)hi;
     }
-    to_axes<RANK>(g->out_lb, P.olb, 0);
-    to_axes<RANK>(g->region_lb, rlb, 0);
-    to_axes<RANK>(g->region_ub, rub, 1);
-    P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];
-    int variant = cfg ? cfg->variant : 0;
-    if (variant < 0 || variant >= march_variant_count(RANK)) variant = 0;
+    axes(g->out_lb, P.olb, 0);
+    if (jk) { P.rI0 = 0; P.rI1 = 1; }
+    else {
+      to_axes<RANK>(g->region_lb, rlb, 0);
+      to_axes<RANK>(g->region_ub, rub, 1);
+      P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];
+    }
     launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
     return NEPTUNE_HIP_OK;
   }

@@ -101,10 +101,12 @@ __device__ __forceinline__ T scalar_load(const T* p) {
 }
 
 // ---- accessor handed to the body for the cell (row r, element e) of the wave tile -----
-template <class T, int RANK, int NIN, class FP, int RJ, int r, int e>
+// JK (rank 2 only): the field is treated as ONE plane of rows x columns -- (d0,d1) -> (J,K) --
+// instead of marching down the rows -- (d0,d1) -> (I,K).
+template <class T, int RANK, int NIN, class FP, int RJ, int r, int e, bool JK = false>
 struct MarchAcc {
   static constexpr int VK = 16 / sizeof(T);
-  static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  static constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
   static constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
   // K neighbours exist for every live plane (box) or for the centre plane only (star)
   static constexpr int NPH = FP::BOX ? NP : 1;
@@ -119,8 +121,8 @@ struct MarchAcc {
   template <int IN, int... O>
   __device__ __forceinline__ T get() const {
     static_assert(IN >= 0 && IN < NIN, "input index out of range");
-    constexpr int oi = PickOffset<RANK, AxisMap<RANK>::I, O...>::value;
-    constexpr int oj = PickOffset<RANK, AxisMap<RANK>::J, O...>::value;
+    constexpr int oi = JK ? 0 : PickOffset<RANK, AxisMap<RANK>::I, O...>::value;
+    constexpr int oj = JK ? PickOffset<RANK, 0, O...>::value : PickOffset<RANK, AxisMap<RANK>::J, O...>::value;
     constexpr int ok = PickOffset<RANK, AxisMap<RANK>::K, O...>::value;
     if constexpr (IN == HIN) {
       static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2,
@@ -141,7 +143,7 @@ struct MarchAcc {
   __device__ __forceinline__ int64_t idx() const {
     static_assert(D >= 0 && D < RANK, "index argument out of range");
     if constexpr (RANK == 3) return D == 0 ? li : (D == 1 ? lj : lk);
-    else if constexpr (RANK == 2) return D == 0 ? li : lk;
+    else if constexpr (RANK == 2) return D == 0 ? (JK ? lj : li) : lk;
     else return lk;
   }
 };
@@ -161,10 +163,13 @@ struct MarchAcc {
 //         all-global form reached the memory side, FETCH = 1.5x the field for RJ = 4), so
 //         sharing through LDS removes real HBM/fabric traffic, not just L2 hits.  Only the
 //         workgroup's outermost rows still come from global memory.
-template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false>
+//   JK2   rank 2 only: no marching; the field is one plane tiled in (rows, columns).  Waves are
+//         short-lived (load RJ rows + exchanged halo rows, compute, store, exit), like the fastest
+//         plain copy kernel; the J halo goes through LDS.
+template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false, bool JK2_ = false>
 struct Tile {
   static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_;
-  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_;
+  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_;
 };
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -174,7 +179,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   static_assert(PF >= 1, "prefetch distance");
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
-  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  constexpr bool JK = RANK == 2 && TL::JK2;
+  constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
   constexpr bool BOX = FP::BOX;
   constexpr bool HAS_HALO = HIN >= 0;
   constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
@@ -423,7 +429,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         constexpr int e = ec;
         const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
         const bool inside = in_ij && in_k[e];
-        MarchAcc<T, RANK, NIN, FP, RJ, r, e> acc{ring, lft, rgt, pt, li, lj, lk};
+        MarchAcc<T, RANK, NIN, FP, RJ, r, e, JK> acc{ring, lft, rgt, pt, li, lj, lk};
         const T val = body(acc);
         T through;  // copy-through source: input 0 at the same physical index
         if constexpr (HIN == 0) through = ring[R0][r + R1][e];

@@ -31,7 +31,8 @@ def _in_array(inputs: Sequence[DeviceField]):
     return arr
 
 
-def make_cfg(kernel: int = _capi.KERNEL_AUTO, variant: int = 0, chunk: int = 0) -> _capi.LaunchCfg:
+def make_cfg(kernel: int = _capi.KERNEL_AUTO, variant: int = -1, chunk: int = 0) -> _capi.LaunchCfg:
+    """variant -1 = the library's default tile for the stencil shape"""
     return _capi.LaunchCfg(kernel, variant, chunk, 0)
 
 
