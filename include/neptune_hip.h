@@ -202,6 +202,17 @@ int neptune_hip_store_box(int dtype, int rank, const void *src, const int64_t *s
                           void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * 6b. reduce {kind = "sum"}  (lib/Passes/DataflowLowering.cpp:589-698; NeptuneIROps.td:272-299)
+ *    Sum of the temp `src` (box [src_lb,src_ub)) over the logical domain [lb,ub) (NULL = the
+ *    whole temp), accumulated in the element type and returned widened to double.  Blocking.
+ *    The reference sums serially in row-major order; this is a fixed-tree parallel sum: bit-wise
+ *    reproducible run to run, within 2(n-1) eps sum|x| of the serial result.
+ * ---------------------------------------------------------------------------------- */
+int neptune_hip_reduce_sum(int dtype, int rank, const void *src, const int64_t *src_lb,
+                           const int64_t *src_ub, const int64_t *lb, const int64_t *ub,
+                           double *result, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * 7. helpers for tests and the bench (device-side, so 8 GiB fields never cross PCIe)
  * ---------------------------------------------------------------------------------- */
 /* Deterministic field: value depends only on (global linear index + index_offset, seed);

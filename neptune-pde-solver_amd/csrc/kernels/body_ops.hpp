@@ -8,14 +8,14 @@ namespace ops {
 
 // arith.maximumf / minimumf: NaN if either operand is NaN; -0.0 < +0.0
 template <class T>
-__device__ __forceinline__ T maximumf(T a, T b) {
+__host__ __device__ __forceinline__ T maximumf(T a, T b) {
   if (a != a) return a;
   if (b != b) return b;
   if (a == b) return __builtin_signbit(a) ? b : a;
   return a > b ? a : b;
 }
 template <class T>
-__device__ __forceinline__ T minimumf(T a, T b) {
+__host__ __device__ __forceinline__ T minimumf(T a, T b) {
   if (a != a) return a;
   if (b != b) return b;
   if (a == b) return __builtin_signbit(a) ? a : b;
@@ -23,21 +23,21 @@ __device__ __forceinline__ T minimumf(T a, T b) {
 }
 // arith.maxnumf / minnumf: the non-NaN operand if exactly one is NaN
 template <class T>
-__device__ __forceinline__ T maxnumf(T a, T b) {
+__host__ __device__ __forceinline__ T maxnumf(T a, T b) {
   if (a != a) return b;
   if (b != b) return a;
   return a > b ? a : b;
 }
 template <class T>
-__device__ __forceinline__ T minnumf(T a, T b) {
+__host__ __device__ __forceinline__ T minnumf(T a, T b) {
   if (a != a) return b;
   if (b != b) return a;
   return a < b ? a : b;
 }
-__device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
-__device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
-__device__ __forceinline__ double absf(double x) { return ::fabs(x); }
-__device__ __forceinline__ float absf(float x) { return ::fabsf(x); }
+__host__ __device__ __forceinline__ double sqrt(double x) { return ::sqrt(x); }
+__host__ __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
+__host__ __device__ __forceinline__ double absf(double x) { return ::fabs(x); }
+__host__ __device__ __forceinline__ float absf(float x) { return ::fabsf(x); }
 
 }  // namespace ops
 }  // namespace neptune_hip

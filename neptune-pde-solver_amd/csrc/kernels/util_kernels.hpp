@@ -83,4 +83,75 @@ __global__ __launch_bounds__(256) void neptune_count_mismatch(const U* __restric
   if ((threadIdx.x & (kWave - 1)) == 0 && local) atomicAdd(out, local);
 }
 
+// ---- neptune_ir.reduce {kind = "sum"} (lib/Passes/DataflowLowering.cpp:589-698) ------------------
+// The reference sums serially in row-major order.  A GPU cannot keep that order; this reduction
+// uses a FIXED tree instead (lane-strided partial sums -> wave shuffle tree -> LDS -> one partial
+// per workgroup -> second kernel adds the partials in index order), so the result is bit-for-bit
+// reproducible from run to run and independent of scheduling (no atomics), but differs from the
+// serial sum by rounding: |gpu - serial| <= 2 (n-1) eps sum|x_i| (each order is within (n-1) eps
+// sum|x_i| of the exact sum).  Accumulation is in the element type, like the reference.
+struct ReduceBoxParams {
+  int64_t ext[3];     // reduced box extents (I,J,K order, absent axes 1)
+  int64_t off[3];     // box origin - buffer origin
+  int64_t shape[3];   // buffer extents
+};
+
+template <class T>
+__device__ __forceinline__ T block_sum(T v, T* lds /* >= blockDim.x / 64 entries */) {
+  for (int o = kWave / 2; o > 0; o >>= 1) v += __shfl_down(v, o);
+  const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+  if (lane == 0) lds[w] = v;
+  __syncthreads();
+  T r = 0;
+  if (threadIdx.x == 0) {
+    const int nw = blockDim.x / kWave;
+    for (int i = 0; i < nw; ++i) r += lds[i];  // fixed order
+  }
+  return r;  // valid in thread 0
+}
+
+// contiguous buffer: every workgroup owns one contiguous slice, lanes stride through it
+template <class T>
+__global__ __launch_bounds__(256) void neptune_reduce_partial_flat(const T* __restrict__ src, int64_t count,
+                                                                    T* __restrict__ partials) {
+  __shared__ T lds[4];
+  const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < count ? lo + per : count;
+  T acc = 0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += src[i];
+  const T r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+// sub-box of a buffer: flat index over the box, decoded to buffer coordinates
+template <class T>
+__global__ __launch_bounds__(256) void neptune_reduce_partial_box(const T* __restrict__ src, ReduceBoxParams P,
+                                                                   T* __restrict__ partials) {
+  __shared__ T lds[4];
+  const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
+  const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < total ? lo + per : total;
+  T acc = 0;
+  for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) {
+    const int64_t row = f / P.ext[2];
+    const int64_t k = f - row * P.ext[2];
+    const int64_t j = row % P.ext[1];
+    const int64_t i = row / P.ext[1];
+    acc += src[((i + P.off[0]) * P.shape[1] + (j + P.off[1])) * P.shape[2] + (k + P.off[2])];
+  }
+  const T r = block_sum(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = r;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void neptune_reduce_final(const T* __restrict__ partials, int n, T* __restrict__ out) {
+  __shared__ T lds[4];
+  T acc = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) acc += partials[i];
+  const T r = block_sum(acc, lds);
+  if (threadIdx.x == 0) *out = r;
+}
+
 }  // namespace neptune_hip

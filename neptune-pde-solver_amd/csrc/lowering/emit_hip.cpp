@@ -119,8 +119,16 @@ struct Emitter {
   bool emit_region_ops(const Block& blk, std::ostringstream& o, const std::string& ind,
                        const std::map<std::string, int>& temp_index, const std::map<std::string, int>& index_arg,
                        const std::vector<std::string>* if_results) {
-    for (auto& opp : blk.ops) {
-      const Op& op = *opp;
+    for (auto& opp : blk.ops)
+      if (!emit_op(*opp, o, ind, temp_index, index_arg, if_results)) return false;
+    return true;
+  }
+
+  // one scalar op -> one C++ statement (also used for scalar arithmetic at function level, where
+  // the same text is valid host code)
+  bool emit_op(const Op& op, std::ostringstream& o, const std::string& ind, const std::map<std::string, int>& temp_index,
+               const std::map<std::string, int>& index_arg, const std::vector<std::string>* if_results) {
+    {
       const std::string& n = op.name;
       auto val = [&](const std::string& v) -> std::string {
         auto it = index_arg.find(v);
@@ -293,7 +301,10 @@ struct Emitter {
     for (auto& t : f.arg_types)
       if (!(t.kind == TypeKind::MemRef || t.is_tempish())) { why = "argument of type " + t.str() + " (only memref / temp / field arguments are lowered)"; return false; }
     for (auto& t : f.result_types)
-      if (!(t.kind == TypeKind::MemRef || t.is_tempish())) { why = "result of type " + t.str(); return false; }
+      if (!(t.kind == TypeKind::MemRef || t.is_tempish() || (t.is_scalar() && (t.elem == "f64" || t.elem == "f32")))) {
+        why = "result of type " + t.str();
+        return false;
+      }
     for (auto& t : f.arg_types) {
       if (t.rank() < 1 || t.rank() > 3) { why = "rank " + std::to_string(t.rank()) + " argument"; return false; }
       if (t.elem != "f64" && t.elem != "f32") { why = "element type " + t.elem; return false; }
@@ -359,8 +370,8 @@ struct Emitter {
     o << "// ---- @" << f.name << " (line " << f.line << ") ----\n";
     o << "static nl::Val " << impl << "(nl::Scope& sc";
     for (int i = 0; i < nargs; ++i) o << ", const nl::Val& " << cname(f.body.args[i].name);
-    o << ", const nl::Val* dest, int* ret_arg) {\n";
-    o << "  (void)dest; if (ret_arg) *ret_arg = -1;\n";
+    o << ", const nl::Val* dest, int* ret_arg, double* sret) {\n";
+    o << "  (void)dest; (void)sret; if (ret_arg) *ret_arg = -1;\n";
     int apply_counter = 0;
     for (size_t oi = 0; oi < f.body.ops.size(); ++oi) {
       const Op& op = *f.body.ops[oi];
@@ -424,7 +435,7 @@ struct Emitter {
         o << "  // " << n << " @" << op.callee << "\n";
         o << "  const nl::Val " << cname(op.results[0]) << " = " << op.callee << "__impl(sc";
         for (auto& a : op.operands) o << ", " << cname(a);
-        o << ", " << dest << ", nullptr);\n";
+        o << ", " << dest << ", nullptr, nullptr);\n";
       } else if (n == "neptune_ir.store") {
         const Type& vt = op.types[0];
         o << "  // neptune_ir.store " << op.operands[0] << " to " << op.operands[1] << "\n";
@@ -436,11 +447,22 @@ struct Emitter {
           o << "  nl::run_store(sc, " << cname(op.operands[0]) << ", " << cname(op.operands[1]) << ", nullptr, "
             << dtype_macro(vt.elem) << ");\n";
         }
-      } else if (n == "arith.constant") {
-        // scalar constants at function level only feed solver ops, which are not lowered here
+      } else if (n == "neptune_ir.reduce") {
+        const Type& in = op.types[0];
+        o << "  // neptune_ir.reduce " << op.operands[0] << " {kind = \"sum\"}   (fixed-tree device sum, blocking)\n";
+        std::string bx = "nullptr";
+        if (op.attrs.count("bounds")) bx = "&" + new_box(op.attrs.at("bounds").bounds);
+        o << "  const " << ctype(in.elem) << " " << cname(op.results[0]) << " = (" << ctype(in.elem) << ")nl::run_reduce_sum(sc, "
+          << cname(op.operands[0]) << ", " << bx << ", " << dtype_macro(in.elem) << ");\n";
+      } else if ((n.compare(0, 6, "arith.") == 0 || n.compare(0, 5, "math.") == 0) && op.regions.empty()) {
+        // scalar arithmetic at function level (constants, reduce results): plain host statements
+        static const std::map<std::string, int> none;
+        if (!emit_op(op, o, "  ", none, none, nullptr)) return false;
       } else if (n == "neptune_ir.return" || n == "func.return" || n == "return") {
         if (op.operands.empty()) {
           o << "  return nl::Val{};\n";
+        } else if (f.result_types[0].is_scalar()) {
+          o << "  if (sret) *sret = (double)" << cname(op.operands[0]) << ";\n  return nl::Val{};\n";
         } else {
           const int root = vals[op.operands[0]].root_arg;
           if (root >= 0) o << "  if (ret_arg) *ret_arg = " << root << ";\n";
@@ -452,8 +474,11 @@ struct Emitter {
 
     // exported symbol with the expanded-memref ABI
     const bool has_res = !f.result_types.empty();
-    const int rrank = has_res ? f.result_types[0].rank() : 0;
-    o << "extern \"C\" " << (has_res ? "NeptuneMemRef" + std::to_string(rrank) + "D" : std::string("void")) << " " << f.name << "(";
+    const bool scalar_res = has_res && f.result_types[0].is_scalar();
+    const int rrank = (has_res && !scalar_res) ? f.result_types[0].rank() : 0;
+    o << "extern \"C\" "
+      << (scalar_res ? ctype(f.result_types[0].elem) : has_res ? "NeptuneMemRef" + std::to_string(rrank) + "D" : std::string("void"))
+      << " " << f.name << "(";
     for (int i = 0; i < nargs; ++i) {
       const int r = f.arg_types[i].rank();
       const std::string a = "a" + std::to_string(i);
@@ -484,12 +509,14 @@ struct Emitter {
               << " has the wrong static extent\");\n";
       }
     }
-    o << "  int ret_arg = -1;\n";
-    o << "  " << (has_res ? "const nl::Val r = " : "") << impl << "(sc";
+    o << "  int ret_arg = -1;\n  double sret = 0.0;\n";
+    o << "  " << ((has_res && !scalar_res) ? "const nl::Val r = " : "") << impl << "(sc";
     for (int i = 0; i < nargs; ++i) o << ", m" << i;
-    o << ", nullptr, &ret_arg);\n";
+    o << ", nullptr, &ret_arg, &sret);\n";
     o << "  sc.finish();\n";
-    if (has_res) {
+    if (scalar_res) {
+      o << "  return (" << ctype(f.result_types[0].elem) << ")sret;\n";
+    } else if (has_res) {
       const std::string mr = "NeptuneMemRef" + std::to_string(rrank) + "D";
       o << "  " << mr << " out;\n";
       // result aliases an argument (e.g. @entry returns unwrap of its destination field): hand the
@@ -514,11 +541,11 @@ struct Emitter {
     sig.name = f.name;
     auto conv = [](const Type& t) {
       SigType st;
-      st.kind = t.kind == TypeKind::MemRef ? "memref" : (t.kind == TypeKind::Temp ? "temp" : "field");
+      st.kind = t.kind == TypeKind::MemRef ? "memref" : (t.kind == TypeKind::Temp ? "temp" : (t.is_scalar() ? "scalar" : "field"));
       st.elem = t.elem;
       st.rank = t.rank();
       if (t.kind == TypeKind::MemRef) st.shape = t.shape;
-      else {
+      else if (t.is_tempish()) {
         for (int d = 0; d < t.rank(); ++d) { st.shape.push_back(t.bounds.ub[d] - t.bounds.lb[d]); st.lb.push_back(t.bounds.lb[d]); }
       }
       return st;
@@ -540,7 +567,7 @@ struct Emitter {
       todo.push_back(f.get());
       fwd << "static nl::Val " << f->name << "__impl(nl::Scope& sc";
       for (size_t i = 0; i < f->arg_types.size(); ++i) fwd << ", const nl::Val&";
-      fwd << ", const nl::Val* dest, int* ret_arg);\n";
+      fwd << ", const nl::Val* dest, int* ret_arg, double* sret);\n";
     }
     for (auto* f : todo)
       if (!emit_function(*f)) return false;

@@ -386,6 +386,16 @@ struct Parser {
       op.types = {a, b};
       return true;
     }
+    if (n == "neptune_ir.reduce") {
+      // $input (`in` $bounds^)? attr-dict `:` type($input) `->` type($result)   (NeptuneIROps.td:293-296)
+      op.operands.push_back(next().text);
+      if (accept("in")) { AttrValue b; if (!parse_attr_value(b)) return false; op.attrs["bounds"] = b; }
+      if (is("{")) { if (!parse_attr_dict(op.attrs)) return false; }
+      Type a, b;
+      if (!expect(":") || !parse_type(a) || !expect("->") || !parse_type(b)) return false;
+      op.types = {a, b};
+      return true;
+    }
     if (n == "neptune_ir.apply_linear" || n == "neptune_ir.apply_nonlinear") {
       // $op `(` $inputs `)` attr-dict `:` functional-type($inputs, $results)   (NeptuneIROps.td:482-485)
       op.callee = next().text.substr(1);

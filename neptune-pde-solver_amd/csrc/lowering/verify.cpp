@@ -33,6 +33,53 @@ struct Verifier {
     return true;
   }
 
+  // arith / math ops on scalars: operand types must match the declared type
+  bool check_arith(const Op& op, Scope& sc) {
+    const std::string& n = op.name;
+    std::vector<Type> ots;
+    for (auto& v : op.operands) { Type t; if (!lookup(sc, op, v, t)) return false; ots.push_back(t); }
+    auto need = [&](size_t k) { if (ots.size() != k) { diag.fail(op.line, "'" + n + "' expects " + std::to_string(k) + " operands"); return false; } return true; };
+    const Type decl = op.types.empty() ? Type{} : op.types[0];
+    static const std::set<std::string> binf = {"arith.addf", "arith.subf", "arith.mulf", "arith.divf", "arith.maximumf",
+                                               "arith.minimumf", "arith.maxnumf", "arith.minnumf"};
+    static const std::set<std::string> bini = {"arith.addi", "arith.subi", "arith.muli", "arith.andi", "arith.ori", "arith.xori"};
+    static const std::set<std::string> unf = {"arith.negf", "math.sqrt", "math.absf"};
+    if (binf.count(n)) {
+      if (!need(2)) return false;
+      if (!is_float(decl) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its floating-point type"); return false; }
+      sc[op.results.at(0)] = decl;
+    } else if (bini.count(n)) {
+      if (!need(2)) return false;
+      if (!is_intlike(decl) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its integer type"); return false; }
+      sc[op.results.at(0)] = decl;
+    } else if (unf.count(n)) {
+      if (!need(1)) return false;
+      if (!is_float(decl) || ots[0] != decl) { diag.fail(op.line, "'" + n + "' operand type must equal its floating-point type"); return false; }
+      sc[op.results.at(0)] = decl;
+    } else if (n == "arith.cmpi" || n == "arith.cmpf") {
+      if (!need(2)) return false;
+      const bool f = n == "arith.cmpf";
+      if ((f ? !is_float(decl) : !is_intlike(decl)) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its declared type"); return false; }
+      static const std::set<std::string> pi = {"eq", "ne", "slt", "sle", "sgt", "sge", "ult", "ule", "ugt", "uge"};
+      static const std::set<std::string> pf = {"oeq", "ogt", "oge", "olt", "ole", "one", "ord", "ueq", "ugt", "uge", "ult", "ule", "une", "uno"};
+      if (!(f ? pf : pi).count(op.predicate)) { diag.fail(op.line, "unknown predicate '" + op.predicate + "'"); return false; }
+      sc[op.results.at(0)] = scalar("i1");
+    } else if (n == "arith.select") {
+      if (!need(3)) return false;
+      if (!(ots[0].is_scalar() && ots[0].elem == "i1") || ots[1] != decl || ots[2] != decl) { diag.fail(op.line, "arith.select operand types"); return false; }
+      sc[op.results.at(0)] = decl;
+    } else if (n == "arith.index_cast" || n == "arith.sitofp" || n == "arith.uitofp" || n == "arith.fptosi" ||
+               n == "arith.extf" || n == "arith.truncf" || n == "arith.extsi" || n == "arith.trunci") {
+      if (!need(1)) return false;
+      if (op.types.size() != 2 || ots[0] != op.types[0] || !op.types[1].is_scalar()) { diag.fail(op.line, "'" + n + "' needs `: from to to` scalar types matching its operand"); return false; }
+      sc[op.results.at(0)] = op.types[1];
+    } else {
+      diag.fail(op.line, "unsupported operation '" + n + "' inside an apply region");
+      return false;
+    }
+    return true;
+  }
+
   // ---- scalar ops inside an apply region (recursively through scf.if) --------------------
   bool check_region_ops(const Block& blk, Scope sc, const Op& apply, int rank, bool linear, bool top,
                         const Type& elem_ty, std::vector<Type>* yielded) {
@@ -100,48 +147,7 @@ struct Verifier {
         for (size_t i = 0; i < op.results.size(); ++i) sc[op.results[i]] = op.types[i];
         continue;
       }
-      // remaining arith / math ops: operand types must match the declared type
-      std::vector<Type> ots;
-      for (auto& v : op.operands) { Type t; if (!lookup(sc, op, v, t)) return false; ots.push_back(t); }
-      auto need = [&](size_t k) { if (ots.size() != k) { diag.fail(op.line, "'" + n + "' expects " + std::to_string(k) + " operands"); return false; } return true; };
-      const Type decl = op.types.empty() ? Type{} : op.types[0];
-      static const std::set<std::string> binf = {"arith.addf", "arith.subf", "arith.mulf", "arith.divf", "arith.maximumf",
-                                                 "arith.minimumf", "arith.maxnumf", "arith.minnumf"};
-      static const std::set<std::string> bini = {"arith.addi", "arith.subi", "arith.muli", "arith.andi", "arith.ori", "arith.xori"};
-      static const std::set<std::string> unf = {"arith.negf", "math.sqrt", "math.absf"};
-      if (binf.count(n)) {
-        if (!need(2)) return false;
-        if (!is_float(decl) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its floating-point type"); return false; }
-        sc[op.results.at(0)] = decl;
-      } else if (bini.count(n)) {
-        if (!need(2)) return false;
-        if (!is_intlike(decl) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its integer type"); return false; }
-        sc[op.results.at(0)] = decl;
-      } else if (unf.count(n)) {
-        if (!need(1)) return false;
-        if (!is_float(decl) || ots[0] != decl) { diag.fail(op.line, "'" + n + "' operand type must equal its floating-point type"); return false; }
-        sc[op.results.at(0)] = decl;
-      } else if (n == "arith.cmpi" || n == "arith.cmpf") {
-        if (!need(2)) return false;
-        const bool f = n == "arith.cmpf";
-        if ((f ? !is_float(decl) : !is_intlike(decl)) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its declared type"); return false; }
-        static const std::set<std::string> pi = {"eq", "ne", "slt", "sle", "sgt", "sge", "ult", "ule", "ugt", "uge"};
-        static const std::set<std::string> pf = {"oeq", "ogt", "oge", "olt", "ole", "one", "ord", "ueq", "ugt", "uge", "ult", "ule", "une", "uno"};
-        if (!(f ? pf : pi).count(op.predicate)) { diag.fail(op.line, "unknown predicate '" + op.predicate + "'"); return false; }
-        sc[op.results.at(0)] = scalar("i1");
-      } else if (n == "arith.select") {
-        if (!need(3)) return false;
-        if (!(ots[0].is_scalar() && ots[0].elem == "i1") || ots[1] != decl || ots[2] != decl) { diag.fail(op.line, "arith.select operand types"); return false; }
-        sc[op.results.at(0)] = decl;
-      } else if (n == "arith.index_cast" || n == "arith.sitofp" || n == "arith.uitofp" || n == "arith.fptosi" ||
-                 n == "arith.extf" || n == "arith.truncf" || n == "arith.extsi" || n == "arith.trunci") {
-        if (!need(1)) return false;
-        if (op.types.size() != 2 || ots[0] != op.types[0] || !op.types[1].is_scalar()) { diag.fail(op.line, "'" + n + "' needs `: from to to` scalar types matching its operand"); return false; }
-        sc[op.results.at(0)] = op.types[1];
-      } else {
-        diag.fail(op.line, "unsupported operation '" + n + "' inside an apply region");
-        return false;
-      }
+      if (!check_arith(op, sc)) return false;
       if (linear && n == "arith.mulf") {
         // VerifyAndAnnotate.cpp:183-186: one factor must be a constant
         auto is_const = [&](const std::string& v) {
@@ -244,7 +250,7 @@ struct Verifier {
       }
       if (linear) {
         static const std::set<std::string> allowed = {"neptune_ir.access", "neptune_ir.apply", "neptune_ir.apply_linear",
-                                                      "neptune_ir.yield", "neptune_ir.return", "arith.addf", "arith.addi",
+                                                      "neptune_ir.yield", "neptune_ir.return", "neptune_ir.reduce", "arith.addf", "arith.addi",
                                                       "arith.subf", "arith.subi", "arith.mulf", "arith.constant"};
         if (!allowed.count(n)) { diag.fail(op.line, "'" + n + "' op operation not allowed in linear_opdef body"); return false; }
       }
@@ -294,6 +300,24 @@ struct Verifier {
         }
       } else if (n == "arith.constant") {
         sc[op.results.at(0)] = op.types.at(0);
+      } else if (n == "neptune_ir.reduce") {
+        Type in;
+        if (!lookup(sc, op, op.operands[0], in)) return false;
+        if (in.kind != TypeKind::Temp || in != op.types.at(0)) { diag.fail(op.line, "'neptune_ir.reduce' op reduce input must be TempType"); return false; }
+        auto kit = op.attrs.find("kind");
+        if (kit == op.attrs.end() || kit->second.kind != AttrValue::String || kit->second.s != "sum") {
+          diag.fail(op.line, "'neptune_ir.reduce' op MVP reduce only supports kind=\"sum\"");
+          return false;
+        }
+        auto bit = op.attrs.find("bounds");
+        if (bit != op.attrs.end() && (bit->second.kind != AttrValue::BoundsK || bit->second.bounds.rank() != in.rank())) {
+          diag.fail(op.line, "'neptune_ir.reduce' op bounds rank mismatch in reduce");
+          return false;
+        }
+        if (!op.types.at(1).is_scalar() || op.types[1].elem != in.elem) { diag.fail(op.line, "'neptune_ir.reduce' op result type must equal the input's element type"); return false; }
+        sc[op.results.at(0)] = op.types[1];
+      } else if ((n.compare(0, 6, "arith.") == 0 || n.compare(0, 5, "math.") == 0) && op.regions.empty()) {
+        if (!check_arith(op, sc)) return false;   // scalar arithmetic on reduce results / constants
       } else if (n == "neptune_ir.return" || n == "func.return" || n == "return") {
         if (oi + 1 != f.body.ops.size()) { diag.fail(op.line, "return must be the last operation of @" + f.name); return false; }
         if (opdef && n != "neptune_ir.return") { diag.fail(op.line, "@" + f.name + ": body must terminate with neptune_ir.return"); return false; }

@@ -275,6 +275,16 @@ inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* boun
   sc.mark_dirty(dst);
 }
 
+// neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
+inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds, int dtype) {
+  double r = 0.0;
+  const int rc = neptune_hip_reduce_sum(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, bounds ? bounds->lb : nullptr,
+                                        bounds ? bounds->ub : nullptr, &r, sc.stream());
+  if (rc == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");
+  if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.reduce rejected");
+  return r;
+}
+
 template <int RANK> struct MemRefOf;
 template <> struct MemRefOf<1> { typedef NeptuneMemRef1D type; };
 template <> struct MemRefOf<2> { typedef NeptuneMemRef2D type; };

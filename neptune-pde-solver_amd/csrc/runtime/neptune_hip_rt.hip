@@ -30,7 +30,9 @@ struct RuntimeState {
   char arch[256] = "unknown";
   int cus = 0;
   unsigned long long* counter = nullptr;  // device word for count_mismatch
+  void* reduce_ws = nullptr;              // kReduceBlocks partials + 1 result (8 B each)
 };
+constexpr int kReduceBlocks = 2048;       // 8 workgroups per CU, fixed: the summation tree never changes
 RuntimeState& rt() {
   static RuntimeState s;
   return s;
@@ -106,6 +108,7 @@ void neptune_hip_init(int device) {
   if (strncmp(s.arch, "gfx950", 6) != 0)
     fprintf(stderr, "[NeptuneRT][HIP] warning: built for gfx950, device reports %s\n", s.arch);
   if (!s.counter) NEPTUNE_HIP_CHECK(hipMalloc((void**)&s.counter, sizeof(unsigned long long)));
+  if (!s.reduce_ws) NEPTUNE_HIP_CHECK(hipMalloc(&s.reduce_ws, (kReduceBlocks + 1) * 8));
   s.device = device;
   s.inited = true;
 }
@@ -117,6 +120,10 @@ void neptune_hip_finalize(void) {
   if (s.counter) {
     (void)hipFree(s.counter);
     s.counter = nullptr;
+  }
+  if (s.reduce_ws) {
+    (void)hipFree(s.reduce_ws);
+    s.reduce_ws = nullptr;
   }
   s.inited = false;
 }
@@ -283,6 +290,69 @@ int neptune_hip_store_box(int dtype, int rank, const void* src, const int64_t* s
     hipLaunchKernelGGL(neptune_store_box<float>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
                        (const float*)src, (float*)dst, P);
   NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
+// ---------------------------------------------------------------- reduce
+int neptune_hip_reduce_sum(int dtype, int rank, const void* src, const int64_t* src_lb, const int64_t* src_ub,
+                           const int64_t* lb, const int64_t* ub, double* result, void* stream) {
+  if (!src || !src_lb || !src_ub || !result) return NEPTUNE_HIP_EINVAL;
+  if (rank < 1 || rank > kMaxRank) return NEPTUNE_HIP_EINVAL;
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
+  int64_t ext[3], off[3], shp[3];
+  bool whole = true;
+  int64_t total = 1, count = 1;
+  for (int d = 0; d < rank; ++d) {
+    shp[d] = src_ub[d] - src_lb[d];
+    if (shp[d] <= 0) return NEPTUNE_HIP_EINVAL;
+    const int64_t l = lb ? lb[d] : src_lb[d], u = ub ? ub[d] : src_ub[d];
+    ext[d] = u - l;
+    off[d] = l - src_lb[d];
+    if (ext[d] < 0) return NEPTUNE_HIP_EINVAL;
+    if (ext[d] > 0 && (off[d] < 0 || off[d] + ext[d] > shp[d])) return NEPTUNE_HIP_EOOB;  // memref.load out of range
+    whole = whole && off[d] == 0 && ext[d] == shp[d];
+    total *= ext[d];
+    count *= shp[d];
+  }
+  if (total == 0) {  // empty domain: the reference's loop never runs, the accumulator stays 0
+    *result = 0.0;
+    return NEPTUNE_HIP_OK;
+  }
+  ensure_init();
+  RuntimeState& s = rt();
+  hipStream_t st = as_stream(stream);
+  const int blocks = (int)((total + 255) / 256 < kReduceBlocks ? (total + 255) / 256 : kReduceBlocks);
+  ReduceBoxParams P;
+  auto fill = [&](const int64_t* a, int64_t* o, int64_t f) {
+    o[0] = o[1] = o[2] = f;
+    if (rank == 3) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; }
+    else if (rank == 2) { o[0] = a[0]; o[2] = a[1]; }
+    else { o[2] = a[0]; }
+  };
+  fill(ext, P.ext, 1);
+  fill(off, P.off, 0);
+  fill(shp, P.shape, 1);
+  if (dtype == NEPTUNE_HIP_F64) {
+    double* part = (double*)s.reduce_ws;
+    if (whole) hipLaunchKernelGGL(neptune_reduce_partial_flat<double>, dim3(blocks), dim3(256), 0, st, (const double*)src, count, part);
+    else hipLaunchKernelGGL(neptune_reduce_partial_box<double>, dim3(blocks), dim3(256), 0, st, (const double*)src, P, part);
+    hipLaunchKernelGGL(neptune_reduce_final<double>, dim3(1), dim3(256), 0, st, part, blocks, part + kReduceBlocks);
+    NEPTUNE_HIP_CHECK(hipGetLastError());
+    double h = 0;
+    NEPTUNE_HIP_CHECK(hipMemcpyAsync(&h, part + kReduceBlocks, sizeof(double), hipMemcpyDeviceToHost, st));
+    NEPTUNE_HIP_CHECK(hipStreamSynchronize(st));
+    *result = h;
+  } else {
+    float* part = (float*)s.reduce_ws;
+    if (whole) hipLaunchKernelGGL(neptune_reduce_partial_flat<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, count, part);
+    else hipLaunchKernelGGL(neptune_reduce_partial_box<float>, dim3(blocks), dim3(256), 0, st, (const float*)src, P, part);
+    hipLaunchKernelGGL(neptune_reduce_final<float>, dim3(1), dim3(256), 0, st, part, blocks, part + kReduceBlocks);
+    NEPTUNE_HIP_CHECK(hipGetLastError());
+    float h = 0;
+    NEPTUNE_HIP_CHECK(hipMemcpyAsync(&h, part + kReduceBlocks, sizeof(float), hipMemcpyDeviceToHost, st));
+    NEPTUNE_HIP_CHECK(hipStreamSynchronize(st));
+    *result = (double)h;
+  }
   return NEPTUNE_HIP_OK;
 }
 

@@ -100,3 +100,17 @@ def count_mismatch(a: DeviceField, b: DeviceField) -> int:
     if n < 0:
         raise RuntimeError("neptune_hip_count_mismatch failed")
     return int(n)
+
+
+def reduce_sum(src: DeviceField, bounds: Optional[Box] = None, stream: Optional[int] = None) -> float:
+    """neptune_ir.reduce %src (in bounds)? {kind = "sum"}  (DataflowLowering.cpp:589-698); blocking"""
+    lib = _capi.load()
+    r = src.rank
+    arr = lambda v: (C.c_int64 * r)(*[int(x) for x in v])
+    out = C.c_double(0.0)
+    rc = lib.neptune_hip_reduce_sum(src.dtype, r, src.ptr, arr(src.lb), arr(src.ub),
+                                    arr(bounds[0]) if bounds is not None else None,
+                                    arr(bounds[1]) if bounds is not None else None, C.byref(out),
+                                    current_stream_ptr() if stream is None else stream)
+    _capi.check(rc, "neptune_hip_reduce_sum")
+    return out.value

@@ -117,7 +117,11 @@ class LoweredModule:
             for a in sig["args"]:
                 argtypes += [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int64] * (2 * a["rank"])
             fn.argtypes = argtypes
-            fn.restype = _capi.MEMREF[sig["result"]["rank"]] if sig["result"] else None
+            res = sig["result"]
+            if res and res["kind"] == "scalar":
+                fn.restype = C.c_double if res["elem"] == "f64" else C.c_float
+            else:
+                fn.restype = _capi.MEMREF[res["rank"]] if res else None
 
     @property
     def symbols(self) -> List[str]:
@@ -151,6 +155,8 @@ class LoweredModule:
         ret = fn(*flat)
         if not sig["result"]:
             return None
+        if sig["result"]["kind"] == "scalar":
+            return float(ret)
         shape = tuple(ret.sizes)
         for a in keep:  # result aliases an argument (e.g. @entry returns its destination field)
             p = a.ctypes.data if isinstance(a, np.ndarray) else getattr(a, "tensor", a).data_ptr()

@@ -521,6 +521,18 @@ class Parser:
             self.expect("to")
             op.types.append(self.parse_type())
             return op
+        if name == "neptune_ir.reduce":
+            # $input (`in` $bounds^)? attr-dict `:` type($input) `->` type($result)   (NeptuneIROps.td:293-296)
+            op.operands = [self.next().text]
+            if self.accept("in"):
+                op.attrs["bounds"] = self.parse_attr_value()
+            if self.peek().text == "{":
+                op.attrs.update(self.parse_attr_dict())
+            self.expect(":")
+            op.types = [self.parse_type()]
+            self.expect("->")
+            op.types.append(self.parse_type())
+            return op
         if name in ("neptune_ir.apply_linear", "neptune_ir.apply_nonlinear"):
             op.attrs["callee"] = self.next().text[1:]
             self.expect("(")
@@ -750,7 +762,7 @@ class Module:
         for a, ty in zip(arrays, f.arg_types):
             args.append(self._bind_arg(a, ty))
         res = self._run_function(f, args)
-        outs = tuple(r.data for r in res)
+        outs = tuple(r.data if isinstance(r, Buffer) else r for r in res)
         if not outs:
             return None
         return outs[0] if len(outs) == 1 else outs
@@ -804,6 +816,11 @@ class Module:
                 return [env[o] for o in op.operands]
             elif n == "arith.constant":
                 env[op.results[0]] = _const(op)
+            elif n == "neptune_ir.reduce":
+                env[op.results[0]] = self._reduce(op, env[op.operands[0]])
+            elif (n.startswith("arith.") or n.startswith("math.")) and not op.regions:
+                # scalar arithmetic on reduce results / constants at function level
+                self._eval_block([op], env, None, "", partial=True)
             elif op.attrs.get("opaque"):
                 raise Unsupported(
                     f"{n}: outside the stencil hot path (solver / time-stepping surface); the oracle "
@@ -828,6 +845,28 @@ class Module:
                 if b.ub[d] > b.lb[d] and (s.start < 0 or s.stop > n_):
                     raise OutOfBounds("store bounds leave a buffer")
         dst.data[tuple(sl_d)] = src.data[tuple(sl_s)]
+
+    # ---- reduce {kind = "sum"} (:589-698): serial left-to-right sum in row-major order -----------
+    def _reduce(self, op: Op, src: Buffer):
+        kind = op.attrs.get("kind")
+        if kind != "sum":
+            raise Unsupported('MVP reduce only supports kind="sum"')
+        b = op.attrs.get("bounds")
+        rank = src.data.ndim
+        lb = b.lb if isinstance(b, Bounds) else src.lb
+        ub = b.ub if isinstance(b, Bounds) else tuple(l + n for l, n in zip(src.lb, src.data.shape))
+        sl = []
+        for d in range(rank):
+            lo, hi = lb[d] - src.lb[d], ub[d] - src.lb[d]
+            if hi > lo and (lo < 0 or hi > src.data.shape[d]):
+                raise OutOfBounds("reduce bounds leave the input buffer")
+            sl.append(slice(lo, hi))
+        x = np.ascontiguousarray(src.data[tuple(sl)]).reshape(-1)
+        dt = src.data.dtype.type
+        if x.size == 0:
+            return dt(0)
+        # acc = 0; acc = acc + x[0]; acc = acc + x[1]; ...  np.cumsum is exactly this sequential chain
+        return np.cumsum(np.concatenate([np.zeros(1, dt), x]), dtype=dt)[-1]
 
     # ---- apply (:258-448) ---------------------------------------------------------------
     def _apply(self, op: Op, inputs: List[Buffer]) -> Buffer:
@@ -879,8 +918,9 @@ class Module:
             return pts.index(v[1])
         return v
 
-    def _eval_block(self, ops: List[Op], env: Dict[str, object], pts: PointSet, elem: str):
-        """evaluate ops in textual order; returns the yielded value(s) (first one)"""
+    def _eval_block(self, ops: List[Op], env: Dict[str, object], pts: PointSet, elem: str, partial: bool = False):
+        """evaluate ops in textual order; returns the yielded value(s) (first one).
+        partial=True: a run of plain ops without terminator (function-level scalar arithmetic)"""
         for op in ops:
             n = op.name
             if n == "neptune_ir.access":
@@ -953,6 +993,8 @@ class Module:
                 return vals
             else:
                 raise Unsupported(f"{n} inside an apply region")
+        if partial:
+            return None
         raise OracleError("region has no terminator")
 
     def _eval_if(self, op: Op, env, pts: PointSet, elem: str):

@@ -63,7 +63,7 @@ def test_emitted_host_code_shape():
     m = re.search(r'extern "C" NeptuneMemRef3D entry\((.*?)\) \{', src)
     assert m and m.group(1).count("int64_t") == 2 * (1 + 2 * 3) and m.group(1).count("void*") == 4
     # apply_linear became a call of the internal implementation, the store hands its field as destination
-    assert "lap3d__impl(sc, v_u0, &v_fout, nullptr)" in src
+    assert "lap3d__impl(sc, v_u0, &v_fout, nullptr, nullptr)" in src
     assert "nl::run_store(sc, v_y, v_fout, nullptr, NEPTUNE_HIP_F64)" in src
     assert "Footprint<0, 1, 1, 1, false, true>" in src
     sig = {s["name"]: s for s in report["signatures"]}
@@ -148,3 +148,46 @@ def test_emitted_modules_compile_for_gfx950(tmp_path, monkeypatch):
             assert hasattr(mod.lib, sym)
         again = lowering.compile_module(text)     # second call is a cache hit (same file, no recompile)
         assert again.path == mod.path
+
+
+NORM = '''
+#l = #neptune_ir.location<"cell">
+!t = !neptune_ir.temp<element = f64, bounds = #neptune_ir.bounds<lb = [0, 0], ub = [{n0}, {n1}]>, location = #l>
+!f = !neptune_ir.field<element = f64, bounds = #neptune_ir.bounds<lb = [0, 0], ub = [{n0}, {n1}]>, location = #l>
+module {{
+  func.func @norm2(%a: memref<?x?xf64>) -> f64 {{
+    %fa = neptune_ir.wrap %a : memref<?x?xf64> -> !f
+    %u = neptune_ir.load %fa : !f -> !t
+    %sq = neptune_ir.apply(%u) attributes {{bounds = #neptune_ir.bounds<lb = [0, 0], ub = [{n0}, {n1}]>}} : (!t) -> !t {{
+      ^bb0(%i: index, %j: index, %x: !t):
+        %v = neptune_ir.access %x[0, 0] : !t -> f64
+        %p = arith.mulf %v, %v : f64
+        neptune_ir.yield %p : f64
+    }}
+    %s = neptune_ir.reduce %sq in #neptune_ir.bounds<lb = [1, 1], ub = [{m0}, {m1}]> {{kind = "sum"}} : !t -> f64
+    %r = math.sqrt %s : f64
+    func.return %r : f64
+  }}
+}}
+'''
+
+
+def test_reduce_and_scalar_results_lower():
+    """SURVEY 8(f) rank 1: neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698) + scalar
+    arithmetic and a scalar function result"""
+    text = NORM.format(n0=6, n1=8, m0=5, m1=7)
+    src, report = lowering.to_hip(text)
+    assert 'extern "C" double norm2(' in src
+    assert "nl::run_reduce_sum(sc, v_sq, &kBox" in src and "neptune_hip::ops::sqrt(v_s)" in src
+    assert report["signatures"][0]["result"]["kind"] == "scalar"
+    with pytest.raises(lowering.LoweringError, match='MVP reduce only supports kind="sum"'):
+        lowering.verify(text.replace('kind = "sum"', 'kind = "max"'))
+    # oracle: serial left-to-right sum in row-major order, exactly
+    import math
+    import numpy as np
+    from helpers import oracle
+    a = helpers.hash_field((6, 8), np.float64, seed=2)
+    acc = 0.0
+    for v in (a[1:5, 1:7] * a[1:5, 1:7]).ravel():
+        acc = acc + v
+    assert oracle.Module.parse(text).call("norm2", a) == math.sqrt(acc)
