@@ -39,5 +39,21 @@ __host__ __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
 __host__ __device__ __forceinline__ double absf(double x) { return ::fabs(x); }
 __host__ __device__ __forceinline__ float absf(float x) { return ::fabsf(x); }
 
+// Explicit time_advance: out = s + dt * k with the two roundings the reference's lowering produces
+// (arith.mulf then arith.addf, HighLevelConvertion.cpp:109-110).  Input 0 = state, input 1 = rhs(state).
+template <class T, int RANK>
+struct EulerAxpy {
+  T dt;
+  template <class A>
+  __device__ __forceinline__ T operator()(const A& a) const {
+    T s0, k0;
+    if constexpr (RANK == 1) { s0 = a.template get<0, 0>(); k0 = a.template get<1, 0>(); }
+    else if constexpr (RANK == 2) { s0 = a.template get<0, 0, 0>(); k0 = a.template get<1, 0, 0>(); }
+    else { s0 = a.template get<0, 0, 0, 0>(); k0 = a.template get<1, 0, 0, 0>(); }
+    const T dt_k = dt * k0;
+    return s0 + dt_k;
+  }
+};
+
 }  // namespace ops
 }  // namespace neptune_hip

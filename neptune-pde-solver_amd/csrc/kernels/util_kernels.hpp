@@ -110,16 +110,34 @@ __device__ __forceinline__ T block_sum(T v, T* lds /* >= blockDim.x / 64 entries
   return r;  // valid in thread 0
 }
 
-// contiguous buffer: every workgroup owns one contiguous slice, lanes stride through it
+// contiguous buffer: every workgroup owns one contiguous slice, lanes stride through it with
+// 16-byte loads (VK cells per lane per load, VK independent partial sums per lane)
 template <class T>
 __global__ __launch_bounds__(256) void neptune_reduce_partial_flat(const T* __restrict__ src, int64_t count,
                                                                     T* __restrict__ partials) {
+  constexpr int VK = 16 / sizeof(T);
+  typedef T vec __attribute__((ext_vector_type(VK)));
   __shared__ T lds[4];
-  const int64_t per = (count + gridDim.x - 1) / gridDim.x;
+  // slices are whole numbers of 16-byte words; the last workgroup also takes the scalar tail
+  const int64_t nvec = count / VK;
+  const int64_t per = (nvec + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per;
-  const int64_t hi = lo + per < count ? lo + per : count;
+  const int64_t hi = lo + per < nvec ? lo + per : nvec;
+  const vec* __restrict__ sv = reinterpret_cast<const vec*>(src);
+  T part[VK];
+#pragma unroll
+  for (int e = 0; e < VK; ++e) part[e] = 0;
+#pragma unroll 4
+  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const vec x = sv[i];
+#pragma unroll
+    for (int e = 0; e < VK; ++e) part[e] += x[e];
+  }
   T acc = 0;
-  for (int64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += src[i];
+#pragma unroll
+  for (int e = 0; e < VK; ++e) acc += part[e];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+    for (int64_t i = nvec * VK; i < count; ++i) acc += src[i];
   const T r = block_sum(acc, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }

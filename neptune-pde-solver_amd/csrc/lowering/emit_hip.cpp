@@ -423,6 +423,34 @@ struct Emitter {
         ai.box = fp.box;
         ai.halo_input = fp.halo_input;
         info.applies.push_back(ai);
+      } else if (n == "neptune_ir.time_advance") {
+        // explicit Euler step: k = rhs(state); result = state + dt * k, over the whole box.  The
+        // reference's own explicit lowering (HighLevelConvertion.cpp:77-120) builds exactly this
+        // apply_{linear,nonlinear} + axpy apply pair (its version is 1-D-only and ill-formed).
+        const Type& st = op.types[0];
+        ValueInfo vi;
+        vi.type = st;
+        vi.uses = vals[op.results[0]].uses;
+        vals[op.results[0]] = vi;
+        std::string dest = "nullptr";
+        if (dest_of.count((int)oi)) dest = dest_of[(int)oi];
+        else if ((int)oi == returned_producer) dest = "dest";
+        const std::string tag = f.name + "_ta" + std::to_string(apply_counter++);
+        const std::string bx = new_box(st.bounds);
+        o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";
+        o << "  const nl::Val k_" << tag << " = " << op.callee << "__impl(sc, " << cname(op.operands[0]) << ", nullptr, nullptr, nullptr);\n";
+        o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << ", &k_" << tag << "};\n";
+        o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<double, " << st.rank()
+          << ">, double, " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<double, " << st.rank() << ">{(double)"
+          << cname(op.operands[1]) << "}, " << bx << ", " << bx << ", in_" << tag << ", nl::kPointwiseRadius2, " << dest << ");\n";
+        ApplyInfo ai;
+        ai.function = f.name;
+        ai.tag = tag;
+        ai.rank = st.rank();
+        ai.num_inputs = 2;
+        ai.march = st.rank() >= 2;
+        ai.halo_input = -1;
+        info.applies.push_back(ai);
       } else if (!op.callee.empty()) {
         const Function* c = m.find(op.callee);
         ValueInfo vi;

@@ -386,6 +386,23 @@ struct Parser {
       op.types = {a, b};
       return true;
     }
+    if (n == "neptune_ir.time_advance") {
+      // $state `,` $dt attr-dict `:` type($state) `,` type($dt) `->` type($result)   (NeptuneIROps.td:766-770)
+      parse_operands(op.operands);
+      if (is("{")) { if (!parse_attr_dict(op.attrs)) return false; }
+      Type a, b, c;
+      if (!expect(":") || !parse_type(a) || !expect(",") || !parse_type(b) || !expect("->") || !parse_type(c)) return false;
+      op.types = {a, b, c};
+      // only the explicit method (TimeMethod 0, NeptuneIRAttrs.td:78-85) with an rhs operator is part of
+      // the stencil path; implicit / runtime methods go to the solver runtime on the host
+      auto m = op.attrs.find("method");
+      auto r = op.attrs.find("rhs");
+      const bool is_explicit = m != op.attrs.end() && m->second.kind == AttrValue::Int && m->second.i == 0 &&
+                               r != op.attrs.end() && r->second.kind == AttrValue::Symbol;
+      if (is_explicit) op.callee = r->second.s;
+      else op.opaque = true;
+      return true;
+    }
     if (n == "neptune_ir.reduce") {
       // $input (`in` $bounds^)? attr-dict `:` type($input) `->` type($result)   (NeptuneIROps.td:293-296)
       op.operands.push_back(next().text);

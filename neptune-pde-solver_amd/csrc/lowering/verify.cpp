@@ -267,6 +267,23 @@ struct Verifier {
       } else if (n == "neptune_ir.apply") {
         if (!check_apply(op, sc, linear)) return false;
         sc[op.results.at(0)] = op.types.back();
+      } else if (n == "neptune_ir.time_advance") {
+        // explicit method: result = state + dt * rhs(state)   (HighLevelConvertion.cpp:77-120)
+        Type st, dt;
+        if (op.operands.size() != 2 || !lookup(sc, op, op.operands[0], st) || !lookup(sc, op, op.operands[1], dt)) {
+          diag.fail(op.line, "'neptune_ir.time_advance' op expects a state and a time step");
+          return false;
+        }
+        if (st.kind != TypeKind::Temp || st != op.types.at(0) || op.types.at(2) != st) { diag.fail(op.line, "'neptune_ir.time_advance' op state / result must be the same temp type"); return false; }
+        if (!(dt.is_scalar() && dt.elem == "f64") || op.types.at(1) != dt) { diag.fail(op.line, "'neptune_ir.time_advance' op dt must be f64"); return false; }
+        if (st.elem != "f64") { diag.fail(op.line, "'neptune_ir.time_advance' op explicit method is f64 only (dt is f64)"); return false; }
+        const Function* callee = m.find(op.callee);
+        if (!callee || callee->kind == FuncKind::Func) { diag.fail(op.line, "'neptune_ir.time_advance' op rhs must reference linear_opdef or nonlinear_opdef"); return false; }
+        if (callee->arg_types.size() != 1 || callee->result_types.size() != 1 || callee->arg_types[0] != st || callee->result_types[0] != st) {
+          diag.fail(op.line, "'neptune_ir.time_advance' op rhs @" + op.callee + " must map the state type to itself");
+          return false;
+        }
+        sc[op.results.at(0)] = st;
       } else if (n == "neptune_ir.apply_linear" || n == "neptune_ir.apply_nonlinear") {
         const Function* callee = m.find(op.callee);
         if (!callee) { diag.fail(op.line, "'" + n + "' op unresolved symbol @" + op.callee); return false; }

@@ -275,6 +275,11 @@ inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* boun
   sc.mark_dirty(dst);
 }
 
+// footprint / radius table of a two-input pointwise apply (time_advance's axpy step)
+using PointwiseFP = Footprint<-1, 0, 0, 0, false, true>;
+static const int32_t kPointwiseRadius2[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {
+    {0, 0, 0}, {0, 0, 0}, {-1, -1, -1}, {-1, -1, -1}};
+
 // neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
 inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds, int dtype) {
   double r = 0.0;

@@ -310,7 +310,7 @@ int neptune_hip_reduce_sum(int dtype, int rank, const void* src, const int64_t* 
     off[d] = l - src_lb[d];
     if (ext[d] < 0) return NEPTUNE_HIP_EINVAL;
     if (ext[d] > 0 && (off[d] < 0 || off[d] + ext[d] > shp[d])) return NEPTUNE_HIP_EOOB;  // memref.load out of range
-    whole = whole && off[d] == 0 && ext[d] == shp[d];
+    whole = whole && off[d] == 0 && ext[d] == shp[d] && ((uintptr_t)src % 16 == 0);
     total *= ext[d];
     count *= shp[d];
   }

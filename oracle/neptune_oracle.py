@@ -521,6 +521,21 @@ class Parser:
             self.expect("to")
             op.types.append(self.parse_type())
             return op
+        if name == "neptune_ir.time_advance":
+            # $state `,` $dt attr-dict `:` type($state) `,` type($dt) `->` type($result)   (NeptuneIROps.td:766-770)
+            op.operands = self.parse_operand_list()
+            if self.peek().text == "{":
+                op.attrs.update(self.parse_attr_dict())
+            self.expect(":")
+            op.types = [self.parse_type()]
+            self.expect(",")
+            op.types.append(self.parse_type())
+            self.expect("->")
+            op.types.append(self.parse_type())
+            explicit = op.attrs.get("method") == 0 and isinstance(op.attrs.get("rhs"), tuple)
+            if not explicit:
+                op.attrs["opaque"] = True      # implicit / runtime methods: solver surface
+            return op
         if name == "neptune_ir.reduce":
             # $input (`in` $bounds^)? attr-dict `:` type($input) `->` type($result)   (NeptuneIROps.td:293-296)
             op.operands = [self.next().text]
@@ -818,6 +833,17 @@ class Module:
                 env[op.results[0]] = _const(op)
             elif n == "neptune_ir.reduce":
                 env[op.results[0]] = self._reduce(op, env[op.operands[0]])
+            elif n == "neptune_ir.time_advance" and not op.attrs.get("opaque"):
+                # explicit method: k = rhs(state); out = state + dt * k  (mulf, then addf;
+                # lib/Passes/HighLevelConvertion.cpp:77-120), over the whole box
+                state: Buffer = env[op.operands[0]]
+                dt = env[op.operands[1]]
+                callee = self.funcs.get(op.attrs["rhs"][1])
+                if callee is None:
+                    raise OracleError("time_advance: unresolved rhs symbol")
+                k = self._run_function(callee, [state])[0]
+                dt_k = np.multiply(np.float64(dt), k.data)
+                env[op.results[0]] = Buffer(np.add(state.data, dt_k), state.lb)
             elif (n.startswith("arith.") or n.startswith("math.")) and not op.regions:
                 # scalar arithmetic on reduce results / constants at function level
                 self._eval_block([op], env, None, "", partial=True)

@@ -232,3 +232,25 @@ def test_c_caller_in_the_style_of_the_petsc_matmult_thunk(env, tmp_path):
         got = np.array([float.fromhex(t) for t in p.stdout.split()])
         want = _vec(next(k for k in doc["kats"] if k["name"] == name)["expected"])
         assert bits_equal(got, want), name
+
+
+def test_explicit_time_advance_steps(env):
+    """neptune_ir.time_advance {method = 0, rhs = @lap}: u + dt * lap(u), chained for several steps on
+    device-resident fields (nothing crosses PCIe between steps), bit-exact against the oracle"""
+    lowering, torch = env
+    text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-heat-2d.mlir").read_text()
+    mod = lowering.compile_module(text)
+    m = oracle.Module.parse(text)
+    u = helpers.hash_field((12, 128), np.float64, seed=11)
+    a, b = torch.from_numpy(u).cuda(), torch.zeros((12, 128), dtype=torch.float64, device="cuda")
+    ha, hb = u.copy(), np.zeros_like(u)
+    for _ in range(6):
+        mod.call("step", b, a)
+        m.call("step", hb, ha)
+        a, b, ha, hb = b, a, hb, ha
+    assert bits_equal(a.cpu().numpy(), ha), mismatch_report(a.cpu().numpy(), ha)
+    out = np.zeros_like(u)
+    mod.call("step", out, u)                              # host buffers
+    want = np.zeros_like(u)
+    m.call("step", want, u)
+    assert bits_equal(out, want)

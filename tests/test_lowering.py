@@ -191,3 +191,24 @@ def test_reduce_and_scalar_results_lower():
     for v in (a[1:5, 1:7] * a[1:5, 1:7]).ravel():
         acc = acc + v
     assert oracle.Module.parse(text).call("norm2", a) == math.sqrt(acc)
+
+
+def test_explicit_time_advance_lowers_and_implicit_stays_on_the_host():
+    text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-heat-2d.mlir").read_text()
+    src, report = lowering.to_hip(text)
+    assert report["lowered"] == ["lap", "step"]
+    assert "lap__impl(sc, v_u0, nullptr, nullptr, nullptr)" in src and "EulerAxpy<double, 2>{(double)v_dt}" in src
+    # oracle: out = s + dt*k, two roundings, whole box (copy-through cells see k = s)
+    import numpy as np
+    from helpers import oracle
+    u = helpers.hash_field((12, 128), np.float64, seed=3)
+    out = np.zeros_like(u)
+    oracle.Module.parse(text).call("step", out, u)
+    i, j = 4, 9
+    lap = (((u[i - 1, j] + u[i + 1, j]) + u[i, j - 1]) + u[i, j + 1]) - 4.0 * u[i, j]
+    assert out[i, j] == u[i, j] + 0.1 * lap and out[0, 5] == u[0, 5] + 0.1 * u[0, 5]
+    # implicit methods need the solver runtime: the function is reported, not lowered
+    _, rep2 = lowering.to_hip(text.replace("method = 0 : i32, rhs = @lap", 'method = 2 : i32, system = @lap, solver = "gmres"'))
+    assert rep2["lowered"] == ["lap"] and rep2["skipped"][0]["symbol"] == "step"
+    with pytest.raises(lowering.LoweringError, match="rhs must reference linear_opdef or nonlinear_opdef"):
+        lowering.verify(text.replace("rhs = @lap", "rhs = @nope"))
