@@ -206,11 +206,18 @@ def main():
     # steps start from the same data whatever the ramp did.
     t_ramp = time.perf_counter()
     n_ramp = 0
-    while time.perf_counter() - t_ramp < 0.3 and n_ramp < 2000:
+    while True:
         for s in range(10):
             step(s)
         torch.cuda.synchronize()
         n_ramp += 10
+        go = time.perf_counter() - t_ramp < 0.3 and n_ramp < 2000
+        if world > 1:   # every rank must run the same number of steps (each step is an exchange): rank 0 decides
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+            dist.broadcast(flag, 0)
+            go = bool(int(flag.item()))
+        if not go:
+            break
     bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
     bufs[1].tensor.zero_()
     torch.cuda.synchronize()
