@@ -96,7 +96,7 @@ struct MarchVariant {
   int RJ, WJ, WK;
   bool dpp, nt;
   int PF;
-  bool ntl, ldsj, jk;
+  bool ntl, ldsj, jk, jhl;
   const char* name;
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
@@ -106,50 +106,60 @@ struct MarchVariant {
 // which run every one of them.  Measured on MI355X (profiles/r01_sweep_report.txt):
 //   rank 3, star  : 0  rj4_wj4_wk2_pf2_lds   (1024^3 fp64 7-point: 6.1 TB/s)
 //   rank 3, box   : 1  rj4_wj8_wk1_pf2_lds   (512^3 fp32 27-point: 5.6 TB/s)
+//   rank 3, star of radius 2 : 2  rj2_wj8_wk1_pf2_lds_jhl  (5 live planes: fewer rows per lane,
+//                      J halo rows only for the centre plane, so the tile fits the register file)
 //   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s), and
 //                   1  wk4_pf4, the march form, for launches restricted to a row range
-// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name)
-#define NEPTUNE_MARCH3_DEFAULT(X)                                            \
-  X(0, 4, 4, 2, true, true, 2, false, true, false, "rj4_wj4_wk2_pf2_lds")    \
-  X(1, 4, 8, 1, true, true, 2, false, true, false, "rj4_wj8_wk1_pf2_lds")
+// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)
+#define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
+  X(0, 4, 4, 2, true, true, 2, false, true, false, false, "rj4_wj4_wk2_pf2_lds")    \
+  X(1, 4, 8, 1, true, true, 2, false, true, false, false, "rj4_wj8_wk1_pf2_lds")    \
+  X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
-  X(0, 4, 8, 1, true, true, 1, false, true, true, "tile_rj4_wj8_wk1")        \
-  X(1, 1, 1, 4, true, true, 4, false, false, false, "wk4_pf4")
+  X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
+  X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(2, 4, 4, 1, false, false, 1, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(3, 4, 4, 1, true, true, 2, false, false, false, "rj4_wj4_wk1_pf2")        \
-  X(4, 2, 4, 1, true, true, 2, false, false, false, "rj2_wj4_wk1_pf2")        \
-  X(5, 8, 2, 1, true, true, 1, false, false, false, "rj8_wj2_wk1_pf1")        \
-  X(6, 4, 4, 1, true, true, 1, false, false, false, "rj4_wj4_wk1_pf1")        \
-  X(7, 4, 4, 1, true, true, 2, false, true, false, "rj4_wj4_wk1_pf2_lds")     \
-  X(8, 2, 8, 1, true, true, 4, false, true, false, "rj2_wj8_wk1_pf4_lds")     \
-  X(9, 8, 4, 1, true, true, 1, false, true, false, "rj8_wj4_wk1_pf1_lds")     \
-  X(10, 8, 4, 2, true, true, 1, false, true, false, "rj8_wj4_wk2_pf1_lds")    \
-  X(11, 4, 4, 2, true, true, 3, false, true, false, "rj4_wj4_wk2_pf3_lds")    \
-  X(12, 4, 2, 4, true, true, 2, false, true, false, "rj4_wj2_wk4_pf2_lds")    \
-  X(13, 2, 16, 1, true, true, 3, false, true, false, "rj2_wj16_wk1_pf3_lds")
+  X(3, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(4, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
+  X(5, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2") \
+  X(6, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
+  X(7, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
+  X(8, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
+  X(9, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
+  X(10, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
+  X(11, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
+  X(12, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
+  X(13, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
+  X(14, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
+  X(15, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
+  X(16, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
+  X(17, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
+  X(18, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
+  X(19, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
+  X(20, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
+  X(21, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
-  X(2, 1, 1, 4, false, false, 1, false, false, false, "wk4_pf1_shfl_plainst") \
-  X(3, 1, 1, 4, true, true, 2, false, false, false, "wk4_pf2")  \
-  X(4, 1, 1, 1, true, true, 4, false, false, false, "wk1_pf4")  \
-  X(5, 1, 1, 4, true, true, 8, false, false, false, "wk4_pf8")  \
-  X(6, 4, 16, 1, true, true, 1, false, true, true, "tile_rj4_wj16_wk1")  \
-  X(7, 8, 8, 1, true, true, 1, false, true, true, "tile_rj8_wj8_wk1")    \
-  X(8, 2, 16, 1, true, true, 1, false, true, true, "tile_rj2_wj16_wk1")  \
-  X(9, 4, 4, 2, true, true, 1, false, true, true, "tile_rj4_wj4_wk2")    \
-  X(10, 4, 8, 2, true, true, 1, false, true, true, "tile_rj4_wj8_wk2")   \
-  X(11, 8, 4, 1, true, true, 1, false, true, true, "tile_rj8_wj4_wk1")   \
-  X(12, 4, 4, 1, true, true, 1, false, true, true, "tile_rj4_wj4_wk1")   \
-  X(13, 4, 8, 1, false, false, 1, false, true, true, "tile_rj4_wj8_wk1_shfl_plainst")
+  X(2, 1, 1, 4, false, false, 1, false, false, false, false, "wk4_pf1_shfl_plainst") \
+  X(3, 1, 1, 4, true, true, 2, false, false, false, false, "wk4_pf2")  \
+  X(4, 1, 1, 1, true, true, 4, false, false, false, false, "wk1_pf4")  \
+  X(5, 1, 1, 4, true, true, 8, false, false, false, false, "wk4_pf8")  \
+  X(6, 4, 16, 1, true, true, 1, false, true, true, false, "tile_rj4_wj16_wk1")  \
+  X(7, 8, 8, 1, true, true, 1, false, true, true, false, "tile_rj8_wj8_wk1")    \
+  X(8, 2, 16, 1, true, true, 1, false, true, true, false, "tile_rj2_wj16_wk1")  \
+  X(9, 4, 4, 2, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk2")    \
+  X(10, 4, 8, 2, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk2")   \
+  X(11, 8, 4, 1, true, true, 1, false, true, true, false, "tile_rj8_wj4_wk1")   \
+  X(12, 4, 4, 1, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk1")   \
+  X(13, 4, 8, 1, false, false, 1, false, true, true, false, "tile_rj4_wj8_wk1_shfl_plainst")
 #else
 #define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
 #define NEPTUNE_MARCH2_VARIANTS(X) NEPTUNE_MARCH2_DEFAULT(X)
 #endif
 
-#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name},
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name},
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
@@ -197,9 +207,9 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
 template <class Body, class T, int RANK, int NIN, class FP>
 inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
                          hipStream_t stream) {
-#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, name)                                      \
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)                                 \
   case idx:                                                                                                     \
-    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2>>(     \
+    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL>>( \
         P, body, planes, chunk, stream);                                                                        \
     break;
   if constexpr (RANK == 3) {
@@ -266,7 +276,8 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
     P.out = static_cast<T*>(out);
     // variant < 0 (or no cfg): automatic -- box stencils of rank 3 take their own default tile
     int variant = cfg ? cfg->variant : -1;
-    if (variant < 0 || variant >= march_variant_count(RANK)) variant = (RANK == 3 && FP::BOX) ? 1 : 0;
+    if (variant < 0 || variant >= march_variant_count(RANK))
+      variant = (RANK == 3 && (FP::R0 > 1 || FP::R1 > 1)) ? 2 : (RANK == 3 && FP::BOX) ? 1 : 0;
     // rank-2 tile form: (d0,d1) -> (J,K), one plane.  It cannot restrict rows (the march kernel's
     // region is a plane range), so a row-restricted launch takes the default march form.
     bool jk = RANK == 2 && march_variant(RANK, variant)->jk;

@@ -166,10 +166,13 @@ struct MarchAcc {
 //   JK2   rank 2 only: no marching; the field is one plane tiled in (rows, columns).  Waves are
 //         short-lived (load RJ rows + exchanged halo rows, compute, store, exit), like the fastest
 //         plain copy kernel; the J halo goes through LDS.
-template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false, bool JK2_ = false>
+//   JHL   star stencils: obtain the J halo rows when a plane becomes the centre (see JH_LATE in
+//         the kernel) instead of when it arrives
+template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false, bool JK2_ = false,
+          bool JHL_ = false>
 struct Tile {
   static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_;
-  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_;
+  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_, JHL = JHL_;
 };
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -190,6 +193,15 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // live SGPRs for the 7-point stencil.
   constexpr int NPH = BOX ? NP : 1;
   constexpr int HLEAD = BOX ? R0 : 0;  // halos in flight belong to plane i+1+HLEAD
+  // J halo rows follow the same split.  A box stencil reads them on every live plane: they are
+  // loaded / exchanged when a plane arrives and ride the ring.  A star stencil reads them on the
+  // centre plane only: they are obtained when a plane BECOMES the centre (LDS exchange of the
+  // centre's own rows; workgroup-edge rows fetched PF steps ahead -- one step ahead measured 10 %
+  // slower, the edge waves then stall the whole workgroup at the barrier), so no halo row rides the
+  // ring for the planes between arrival and centre.
+  constexpr bool JH_LATE = TL::JHL && !BOX && R1 > 0;
+  constexpr int PJ = JH_LATE ? R0 : NP - 1;  // plane whose J halo rows are filled at a step
+  constexpr int NJH = R1 > 0 ? 2 * R1 : 1;
   static_assert(R2 <= VK, "K radius larger than one lane's vector is not supported");
   static_assert(HAS_HALO || (R0 == 0 && R1 == 0 && R2 == 0), "pointwise footprint must have zero radii");
   // J-halo exchange through LDS needs a vertical neighbour in the workgroup and a J radius that
@@ -253,6 +265,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   T khl[NPH][NR][NS];       // scalar K halos, left  (wave-uniform)
   T khr[NPH][NR][NS];       // scalar K halos, right
   V nxt[PF][NR];            // planes in flight (slot ph is consumed by steps i == ph mod PF)
+  V njh[PF][NJH];           // star stencils: J halo rows of the next PF centre planes, in flight
   T nkhl[NR][NS], nkhr[NR][NS];
   V pt[NIN][RJ];            // inputs read at offset 0 only, current plane
   V npt[NIN][RJ];           // ... next plane, in flight
@@ -277,12 +290,32 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
           if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
           else rows[s] = *src;
         };
-        if constexpr (LDSJ && !all_rows && s < R1) {
+        constexpr bool halo_row = s < R1 || s >= R1 + RJ;
+        if constexpr (JH_LATE && halo_row) {
+          // star: halo rows are fetched by load_jhalo when the plane becomes the centre
+        } else if constexpr (LDSJ && !all_rows && s < R1) {
           if (wj == 0) ld();           // top rows of the workgroup: no wave above to get them from
         } else if constexpr (LDSJ && !all_rows && s >= R1 + RJ) {
           if (wj == WJ - 1) ld();      // bottom rows of the workgroup
         } else {
           ld();
+        }
+      });
+    }
+  };
+  // star stencils: the 2*R1 J-halo rows of plane ip (x < R1: rows above the tile, else below).  With
+  // the LDS exchange only the workgroup's outermost waves need them from global memory.
+  auto load_jhalo = [&](int32_t ip, V(&jh)[NJH]) {
+    if constexpr (JH_LATE && HAS_HALO) {
+      const char* base = plane_base(P.in[HIN], ip);
+      static_for<2 * R1>([&](auto xc) {
+        constexpr int x = xc;
+        constexpr int s = x < R1 ? x : RJ + x;  // ring slot of that row (R1 + RJ + (x - R1))
+        const bool want = !LDSJ || (x < R1 ? wj == 0 : wj == WJ - 1);
+        if (want) {
+          const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+          if constexpr (NTL) jh[x] = __builtin_nontemporal_load(src);
+          else jh[x] = *src;
         }
       });
     }
@@ -338,6 +371,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     load_rows(ib + R0 + d, nxt[d], std::false_type{});
   });
   load_khalos(ib + HLEAD, nkhl, nkhr);
+  static_for<PF>([&](auto dc) {
+    constexpr int d = dc;
+    load_jhalo(ib + d, njh[d]);
+  });
   load_point_inputs(ib, npt);
 
   // one plane step; `slot` (compile-time) names the in-flight buffer holding plane i+R0, so no
@@ -349,7 +386,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
       constexpr int p = pc;
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
-        ring[p][s] = ring[p + 1][s];
+        if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[p][s] = ring[p + 1][s];
         if constexpr (BOX) {
           static_for<NS>([&](auto xc) {
             constexpr int x = xc;
@@ -361,28 +398,37 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     });
     static_for<NR>([&](auto sc) {
       constexpr int s = sc;
-      ring[NP - 1][s] = nxt[slot][s];
+      if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[NP - 1][s] = nxt[slot][s];
       static_for<NS>([&](auto xc) {
         constexpr int x = xc;
         khl[NPH - 1][s][x] = nkhl[s][x];
         khr[NPH - 1][s][x] = nkhr[s][x];
       });
     });
+    if constexpr (JH_LATE) {
+      // star: the centre plane's halo rows, fetched from global memory PF steps ago (by all waves
+      // without the LDS exchange, by the workgroup's outermost waves with it)
+      static_for<2 * R1>([&](auto xc) {
+        constexpr int x = xc;
+        ring[PJ][x < R1 ? x : RJ + x] = njh[slot][x];
+      });
+    }
     if constexpr (LDSJ) {
-      // J-halo rows of the plane that just arrived: publish my first/last R1 own rows, take the
-      // neighbouring waves' rows.  Double-buffered by step parity, one barrier per step.
+      // J-halo rows of plane PJ (box: the plane that just arrived; star: the plane that just became
+      // the centre): publish my first/last R1 own rows, take the neighbouring waves' rows.
+      // Double-buffered by step parity, one barrier per step.
       const int buf = (i - ib) & 1;
       static_for<R1>([&](auto xc) {
         constexpr int x = xc;
-        lds_rows[buf][w][x][lane] = ring[NP - 1][R1 + x];            // first own rows
-        lds_rows[buf][w][R1 + x][lane] = ring[NP - 1][RJ + x];       // last own rows (s = R1+RJ-R1+x)
+        lds_rows[buf][w][x][lane] = ring[PJ][R1 + x];            // first own rows
+        lds_rows[buf][w][R1 + x][lane] = ring[PJ][RJ + x];       // last own rows (s = R1+RJ-R1+x)
       });
       __syncthreads();
       static_for<R1>([&](auto xc) {
         constexpr int x = xc;
         // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
-        if (wj > 0) ring[NP - 1][x] = lds_rows[buf][w - WK][R1 + x][lane];
-        if (wj < WJ - 1) ring[NP - 1][R1 + RJ + x] = lds_rows[buf][w + WK][x][lane];
+        if (wj > 0) ring[PJ][x] = lds_rows[buf][w - WK][R1 + x][lane];
+        if (wj < WJ - 1) ring[PJ][R1 + RJ + x] = lds_rows[buf][w + WK][x][lane];
       });
     }
     static_for<NIN>([&](auto nc) {
@@ -392,6 +438,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     // refill the slot just consumed with the plane PF steps ahead; K halos and offset-0 inputs
     // are one step ahead
     if (i + PF < ie) load_rows(i + PF + R0, nxt[slot], std::false_type{});
+    if (i + PF < ie) load_jhalo(i + PF, njh[slot]);  // the plane that is the centre PF steps from now
     if (i + 1 < ie) {
       load_khalos(i + 1 + HLEAD, nkhl, nkhr);
       load_point_inputs(i + 1, npt);

@@ -254,3 +254,20 @@ def test_explicit_time_advance_steps(env):
     want = np.zeros_like(u)
     m.call("step", want, u)
     assert bits_equal(out, want)
+
+
+def test_radius_two_star_stencil_on_the_march_kernel(env):
+    """4th-order 13-point Laplacian: 5 live planes, 2-deep J and K halos (LDS exchange of two rows,
+    two-cell wave shifts, two scalar halo cells per side)"""
+    lowering, torch = env
+    text = (helpers.FIXTURE_DIR / "apply-3d-13pt.mlir").read_text()
+    mod = lowering.compile_module(text)
+    assert {a["function"]: a["kernel"] for a in mod.report["applies"]}["lap13"] == "march"
+    u = helpers.hash_field((20, 18, 256), np.float64, seed=13)
+    want = np.zeros_like(u)
+    oracle.Module.parse(text).call("entry", want, u)
+    d_out = torch.zeros(u.shape, dtype=torch.float64, device="cuda")
+    mod.call("entry", d_out, torch.from_numpy(u).cuda())
+    got = d_out.cpu().numpy()
+    assert bits_equal(got, want), mismatch_report(got, want)
+    assert bits_equal(got[:2], u[:2]) and bits_equal(got[:, :, -2:], u[:, :, -2:])   # 2-cell copy-through rim
