@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "march"])
     ap.add_argument("--variant", type=int, default=-1, help="march tile variant (-1 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="march planes per workgroup (0 = auto)")
+    ap.add_argument("--no-autotune", action="store_true",
+                    help="skip the plan-time tuning (untimed, before warm-up) and use the library's default tile")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos before the interior (debug)")
     ap.add_argument("--emulate-rank", default="",
                     help="diagnostic, single process: 'R/W' runs the compute launches rank R of W would issue "
@@ -171,6 +173,19 @@ def main():
     # works on the same data
     bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
     bufs[1].tensor.zero_()
+    # Plan-time tuning, untimed and before any warm-up or timed step: the library times its tiles on
+    # exactly this rank's dominant launch (the interior region of its slab) and keeps the fastest.
+    # Every tile computes the same bits; explicit --variant/--chunk/--kernel switch it off.
+    autotuned = None
+    if not args.no_autotune and args.variant < 0 and args.chunk == 0 and args.kernel == "auto":
+        probe = slab_mod.ShardedApply(sl, body, gbounds, cfg=None)
+        region = probe.interior if (world > 1 or args.emulate_rank) and probe.interior is not None else probe._own_region()
+        cfg, tuned_ms = nh_apply.autotune_builtin(body, [bufs[0]], bufs[1], probe.bounds, region=region)
+        autotuned = {"variant": int(cfg.variant), "chunk": int(cfg.chunk), "ms": tuned_ms}
+        if int(cfg.kernel) == _capi.KERNEL_AUTO:
+            cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
+        bufs[1].tensor.zero_()
+        del probe
     op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap)
     sharded = op
     stream_ptr = fields.current_stream_ptr()
@@ -311,7 +326,8 @@ def main():
                                  + ("" if args.no_overlap else ", overlapped with interior") if world > 1 else "single GPU",
                 "kernel": lib.neptune_hip_kernel_name(plan).decode(),
                 "variant": vname,
-                "chunk": args.chunk,
+                "chunk": int(cfg.chunk),
+                "autotuned": autotuned,
             },
             "hbm_GBps": achieved * world if world > 1 else achieved,
             "roofline": {

@@ -229,6 +229,13 @@ int64_t neptune_hip_count_mismatch(int dtype, const void *a, const void *b, int6
 double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t *g,
                                       const void *const *in, void *out, void *stream,
                                       const neptune_hip_launch_cfg_t *cfg, int warmup, int reps);
+/* Plan-time tuning (in the spirit of FFTW_MEASURE): time every march tile of the library (and a
+ * few chunk lengths) for exactly this geometry and these buffers, and return the fastest
+ * configuration in *best (average ms per launch in *best_ms, may be NULL).  All candidates
+ * produce identical bits; `out` ends up holding the result of a normal launch.  Blocking. */
+int neptune_hip_autotune_builtin(int body, const neptune_hip_apply_geom_t *g, const void *const *in,
+                                 void *out, void *stream, int reps, neptune_hip_launch_cfg_t *best,
+                                 double *best_ms);
 /* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling.
  * mode selects the copy kernel shape (0 .. neptune_hip_copy_mode_count()-1: grid-stride, or
  * 1/2/4/8 loads in flight per lane with optional non-temporal loads/stores). */

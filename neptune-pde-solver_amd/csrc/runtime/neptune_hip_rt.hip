@@ -428,6 +428,40 @@ double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t* 
   return (double)ms / reps;
 }
 
+int neptune_hip_autotune_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                                 void* stream, int reps, neptune_hip_launch_cfg_t* best, double* best_ms) {
+  if (!g || !in || !out || !best) return NEPTUNE_HIP_EINVAL;
+  if (reps <= 0) reps = 5;
+  neptune_hip_launch_cfg_t probe = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
+  const int planned = neptune_hip_apply_builtin_plan(body, g, in, out, &probe);
+  if (planned < 0) return planned;
+  *best = probe;
+  double best_t = neptune_hip_time_apply_builtin(body, g, in, out, stream, &probe, 2, reps);
+  if (best_t < 0) return (int)best_t;
+  if (planned == NEPTUNE_HIP_KERNEL_MARCH) {
+    // every tile the library holds for this rank x a few chunk lengths; all candidates compute the
+    // same bits, so the timed launches leave `out` exactly as a normal launch would
+    const int nv = march_variant_count(g->rank);
+    const int chunks3[] = {0, 32, 64, 128, 256}, chunks2[] = {0};
+    for (int v = 0; v < nv; ++v) {
+      const MarchVariant* mv = march_variant(g->rank, v);
+      const bool tile2 = g->rank == 2 && mv->jk;
+      const int* chunks = (g->rank == 3 || !tile2) ? chunks3 : chunks2;
+      const int nc = (g->rank == 3 || !tile2) ? 5 : 1;
+      for (int c = 0; c < nc; ++c) {
+        neptune_hip_launch_cfg_t cfg = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
+        const double t = neptune_hip_time_apply_builtin(body, g, in, out, stream, &cfg, 1, reps);
+        if (t > 0 && t < best_t) {
+          best_t = t;
+          *best = cfg;
+        }
+      }
+    }
+  }
+  if (best_ms) *best_ms = best_t;
+  return NEPTUNE_HIP_OK;
+}
+
 double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* stream, int mode, int warmup,
                              int reps) {
   if (!dst || !src || reps <= 0 || bytes % 16 != 0) return -1.0;

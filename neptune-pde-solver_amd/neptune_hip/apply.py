@@ -114,3 +114,17 @@ def reduce_sum(src: DeviceField, bounds: Optional[Box] = None, stream: Optional[
                                     current_stream_ptr() if stream is None else stream)
     _capi.check(rc, "neptune_hip_reduce_sum")
     return out.value
+
+
+def autotune_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+                     region: Optional[Box] = None, reps: int = 5, stream: Optional[int] = None):
+    """plan-time tuning: -> (LaunchCfg of the fastest tile/chunk for this geometry, its ms per launch)"""
+    lib = _capi.load()
+    g = geom_for(inputs, out, bounds, region)
+    best = _capi.LaunchCfg(0, -1, 0, 0)
+    ms = C.c_double(0.0)
+    rc = lib.neptune_hip_autotune_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
+                                          current_stream_ptr() if stream is None else stream, reps, C.byref(best),
+                                          C.byref(ms))
+    _capi.check(rc, "neptune_hip_autotune_builtin")
+    return best, ms.value

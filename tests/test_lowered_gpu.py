@@ -271,3 +271,11 @@ def test_radius_two_star_stencil_on_the_march_kernel(env):
     got = d_out.cpu().numpy()
     assert bits_equal(got, want), mismatch_report(got, want)
     assert bits_equal(got[:2], u[:2]) and bits_equal(got[:, :, -2:], u[:, :, -2:])   # 2-cell copy-through rim
+
+
+def test_smoke_script_in_the_shape_of_the_reference_smoke_apply(tmp_path):
+    """tests/smoke_tests/smoke_apply_hip.sh: lower, build, generate the reference's driver, link, run"""
+    p = subprocess.run(["bash", str(helpers.REPO / "tests/smoke_tests/smoke_apply_hip.sh")], capture_output=True, text=True,
+                       env=dict(__import__("os").environ, WORKDIR=str(tmp_path)))
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "SMOKE_OK" in p.stdout and "x[1]=0.000000" in p.stdout and "x[15]=16.000000" in p.stdout

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Time a lowered module's @entry(out, in) on device-resident fields.
+usage: tools/time_module.py <file.mlir> [--reps N]      (field shape comes from the module's types)"""
+import argparse
+import json
+import re
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mlir")
+    ap.add_argument("--symbol", default="entry")
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import torch
+    from neptune_hip import lowering
+    text = Path(args.mlir).read_text()
+    mod = lowering.compile_module(text)
+    sig = mod.signatures[args.symbol]
+    m = re.search(r"#b\s*=\s*#neptune_ir.bounds<lb = \[([^\]]*)\], ub = \[([^\]]*)\]>", text)
+    lb = [int(x) for x in m.group(1).split(",")]
+    ub = [int(x) for x in m.group(2).split(",")]
+    shape = [u - l for l, u in zip(lb, ub)]
+    dt = torch.float64 if sig["args"][0]["elem"] == "f64" else torch.float32
+    a = torch.rand(shape, dtype=dt, device="cuda") * 2 - 1
+    b = torch.zeros(shape, dtype=dt, device="cuda")
+    for _ in range(3):
+        mod.call(args.symbol, b, a)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        mod.call(args.symbol, b, a)          # each call synchronises at exit (ABI: results are ready)
+    torch.cuda.synchronize()
+    dtm = (time.perf_counter() - t0) / args.reps
+    nbytes = 2 * a.numel() * a.element_size()
+    print(json.dumps({"module": args.mlir, "shape": shape, "ms_per_call": dtm * 1e3, "GBps": nbytes / dtm / 1e9,
+                      "applies": mod.report["applies"]}))
+
+
+if __name__ == "__main__":
+    main()
