@@ -36,10 +36,6 @@ namespace neptune_hip {
     }                                                                                        \
   } while (0)
 
-template <class T> struct DTypeOf;
-template <> struct DTypeOf<double> { static constexpr int value = NEPTUNE_HIP_F64; };
-template <> struct DTypeOf<float> { static constexpr int value = NEPTUNE_HIP_F32; };
-
 // ---- geometry checks ------------------------------------------------------------------
 inline int geom_validate(const neptune_hip_apply_geom_t* g) {
   if (!g) return NEPTUNE_HIP_EINVAL;
@@ -139,7 +135,12 @@ struct MarchVariant {
   X(18, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
   X(19, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
   X(20, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
-  X(21, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl")
+  X(21, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
+  X(22, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
+  X(23, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
+  X(24, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
+  X(25, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds") \
+  X(26, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
   X(2, 1, 1, 4, false, false, 1, false, false, false, false, "wk4_pf1_shfl_plainst") \
