@@ -167,10 +167,13 @@ constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr int kNumMarch3 = sizeof(kMarch3) / sizeof(kMarch3[0]);
 constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
 
-inline int march_variant_count(int rank) { return rank == 3 ? kNumMarch3 : (rank == 2 ? kNumMarch2 : 0); }
+// rank 1: a single tile -- the field is one row, a workgroup is 4 waves side by side, every wave
+// loads its 1 KiB, shifts, stores and retires (the access pattern of the fastest copy kernel)
+constexpr MarchVariant kMarch1[] = {{1, 1, 4, true, true, 1, false, false, false, false, "row_wk4"}};
+inline int march_variant_count(int rank) { return rank == 3 ? kNumMarch3 : (rank == 2 ? kNumMarch2 : (rank == 1 ? 1 : 0)); }
 inline const MarchVariant* march_variant(int rank, int v) {
   if (v < 0 || v >= march_variant_count(rank)) return nullptr;
-  return rank == 3 ? &kMarch3[v] : &kMarch2[v];
+  return rank == 3 ? &kMarch3[v] : (rank == 2 ? &kMarch2[v] : &kMarch1[v]);
 }
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -215,6 +218,9 @@ inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, 
     break;
   if constexpr (RANK == 3) {
     switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }
+  } else if constexpr (RANK == 1) {
+    launch_march_variant<Body, T, RANK, NIN, FP, Tile<1, 1, 4, true, true, 1, false, false, false, false>>(P, body, planes,
+                                                                                                        chunk, stream);
   } else {
     switch (variant) { NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_CASE) default: abort(); }
   }
@@ -235,7 +241,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
   const int want = cfg ? cfg->kernel : NEPTUNE_HIP_KERNEL_AUTO;
   if (want == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_KERNEL_DIRECT;
 
-  bool ok = FP::MARCH_OK && RANK >= 2;
+  bool ok = FP::MARCH_OK;
   const int64_t nK = g->out_ub[RANK - 1] - g->out_lb[RANK - 1];
   ok = ok && (nK % VK == 0) && nK >= VK;
   {
@@ -245,7 +251,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
     for (int d = 0; d < RANK; ++d) {
       const int64_t n = g->out_ub[d] - g->out_lb[d];
       ok = ok && n < 0x7fffffffLL;
-      if (d > 0) plane_bytes *= n;
+      if (d > 0 || RANK == 1) plane_bytes *= n;  // rank 1: the single row is the "plane"
     }
     ok = ok && plane_bytes < 0x7fffffffLL;
   }
@@ -255,7 +261,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
     ok = ok && ((uintptr_t)in[k] % 16 == 0);
   }
   ok = ok && ((uintptr_t)out % 16 == 0);
-  for (int d = 1; ok && d < RANK; ++d)
+  for (int d = (RANK == 1 ? 0 : 1); ok && d < RANK; ++d)  // rank 1 has no marched dim to restrict
     ok = ok && g->region_lb[d] == 0 && g->region_ub[d] == g->out_ub[d] - g->out_lb[d];
   if (want == NEPTUNE_HIP_KERNEL_MARCH) return ok ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_EUNSUPPORTED;
   // auto: the march kernel pays off once a row fills at least one wave
@@ -271,7 +277,7 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
   for (int d = 0; d < RANK; ++d)
     if (g->region_lb[d] == g->region_ub[d]) return NEPTUNE_HIP_OK;  // empty region: nothing to do
 
-  if constexpr (FP::MARCH_OK && RANK >= 2) if (kernel == NEPTUNE_HIP_KERNEL_MARCH) {
+  if constexpr (FP::MARCH_OK) if (kernel == NEPTUNE_HIP_KERNEL_MARCH) {
     MarchParams<T, NIN> P{};
     for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
     P.out = static_cast<T*>(out);

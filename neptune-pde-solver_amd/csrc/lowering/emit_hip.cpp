@@ -265,7 +265,7 @@ struct Emitter {
     // the march kernel keeps 2*R0+1 planes of RJ+2*R1 rows in registers: radius 1 for box stencils,
     // up to 2 for star stencils (4th-order 13-point operators); wider footprints use the direct kernel
     const int rmax = fp.box ? 1 : 2;
-    fp.march_ok = rank >= 2 && halo_inputs <= 1 && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
+    fp.march_ok = halo_inputs <= 1 && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
     if (halo_inputs > 1) fp.halo_input = -1, R[0] = R[1] = R[2] = 0;
     if (!fp.march_ok) { fp.halo_input = halo_inputs == 1 ? fp.halo_input : -1; }
 
@@ -451,7 +451,7 @@ struct Emitter {
         ai.tag = tag;
         ai.rank = st.rank();
         ai.num_inputs = 2;
-        ai.march = st.rank() >= 2;
+        ai.march = true;
         ai.halo_input = -1;
         info.applies.push_back(ai);
       } else if (!op.callee.empty()) {

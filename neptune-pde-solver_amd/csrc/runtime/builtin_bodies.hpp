@@ -1,8 +1,8 @@
 // builtin_bodies.hpp -- body functors of the committed fixtures, written exactly as the
 // lowering emits them (one statement per IR op, textual order, no reassociation).  They let
 // the runtime library, the bench and the parity tests exercise the kernels without running
-// the lowering + hipcc first.  tests/test_lowering_emit.py checks that the emitter's output
-// for each fixture is token-for-token this code.
+// the lowering + hipcc first.  tests/test_lowering.py checks that the emitter's output for each
+// fixture is statement-for-statement this code.
 #pragma once
 #include "../kernels/apply_common.hpp"
 
@@ -137,7 +137,7 @@ struct Lap3D27 {
 struct Lap1D3 {
   using T = double;
   static constexpr int RANK = 1, NIN = 1;
-  using FP = Footprint<0, 0, 0, 1, false, /*march*/ false>;
+  using FP = Footprint<0, 0, 0, 1, false>;
   static constexpr int32_t radius[kMaxInputs][kMaxRank] = {{1, 0, 0}, {-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};
   template <class A>
   __device__ __forceinline__ double operator()(const A& a) const {

@@ -66,7 +66,7 @@ def test_host_only_entry_points_work_without_a_gpu(built_libs):
     assert lib.neptune_hip_kernel_name(_capi.KERNEL_DIRECT) == b"neptune_apply_direct"
     assert lib.neptune_hip_march_variant_count(3) >= 1
     assert lib.neptune_hip_march_variant_count(2) >= 1
-    assert lib.neptune_hip_march_variant_count(1) == 0
+    assert lib.neptune_hip_march_variant_count(1) == 1 and lib.neptune_hip_march_variant_count(4) == 0
     names = {lib.neptune_hip_march_variant_name(3, v) for v in range(lib.neptune_hip_march_variant_count(3))}
     assert len(names) == lib.neptune_hip_march_variant_count(3)
     assert lib.neptune_hip_is_device_ptr(None) == 0

@@ -306,3 +306,47 @@ def test_randomised_geometries_bit_exact(nh):
                     mismatch_report(got, want)
             cases += 1
     assert cases == 42
+
+
+LAP1D = '''
+#l = #neptune_ir.location<"cell">
+!t = !neptune_ir.temp<element = f64, bounds = #neptune_ir.bounds<lb = [{lo}], ub = [{hi}]>, location = #l>
+module {{
+  neptune_ir.linear_opdef @ac_lap : (!t) -> !t {{
+  ^bb0(%u: !t):
+    %r = neptune_ir.apply(%u) attributes {{bounds = #neptune_ir.bounds<lb = [{blo}], ub = [{bhi}]>}} : (!t) -> !t {{
+      ^bb0(%i: index, %a: !t):
+        %um1 = neptune_ir.access %a[-1] : !t -> f64
+        %u0 = neptune_ir.access %a[0] : !t -> f64
+        %up1 = neptune_ir.access %a[1] : !t -> f64
+        %two = arith.constant 2.0 : f64
+        %dxinv2 = arith.constant 100.0 : f64
+        %t0 = arith.mulf %two, %u0 : f64
+        %t1 = arith.subf %um1, %t0 : f64
+        %t2 = arith.addf %t1, %up1 : f64
+        %lap_i = arith.mulf %dxinv2, %t2 : f64
+        neptune_ir.yield %lap_i : f64
+    }}
+    neptune_ir.return %r : !t
+  }}
+}}
+'''
+
+
+@pytest.mark.parametrize("n,origin,bounds", [(16, 0, (1, 15)), (130, -7, (-6, 122)), (4096, 0, (1, 4095)), (100000, 3, (500, 99000))])
+def test_rank1_fields_on_both_kernels(nh, n, origin, bounds):
+    """the reference's own inputs are 1-D (@ac_lap, smoke_time_advance.mlir:13-29): a long 1-D field is one
+    row, every wave takes 1 KiB of it (march kernel, single step), neighbours by wave shifts"""
+    text = LAP1D.format(lo=origin, hi=origin + n, blo=bounds[0], bhi=bounds[1])
+    u = helpers.hash_field((n,), np.float64, seed=n)
+    want = helpers.oracle.Module.parse(text).call("ac_lap", u)
+    fin = nh.fields.DeviceField.from_numpy(u, (origin,))
+    for kern in (nh.capi.KERNEL_DIRECT, nh.capi.KERNEL_MARCH, nh.capi.KERNEL_AUTO):
+        fout = nh.fields.DeviceField.empty_like(fin)
+        fout.tensor.fill_(9.0)
+        cfg = nh.apply.make_cfg(kern)
+        nh.apply.apply_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fout, ([bounds[0]], [bounds[1]]), cfg=cfg)
+        nh.torch.cuda.synchronize()
+        assert bits_equal(fout.numpy(), want), f"n={n} kernel={kern}\n" + mismatch_report(fout.numpy(), want)
+    want_plan = nh.capi.KERNEL_MARCH if n >= 128 else nh.capi.KERNEL_DIRECT
+    assert nh.apply.plan_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fout, ([bounds[0]], [bounds[1]])) == want_plan
