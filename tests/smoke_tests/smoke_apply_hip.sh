@@ -2,8 +2,8 @@
 # End-to-end smoke test in the shape of the reference's test/smoke_tests/smoke_apply.sh:
 #   lower the module -> build the kernel library -> generate a tiny C++ driver -> link -> run.
 # The reference pipeline was  neptune-opt --neptuneir-to-llvm | mlir-translate | llvm-as | llc | clang++ ;
-# here steps 1-3 are  neptune-opt --neptuneir-to-hip --emit=so .  The driver is the reference's driver
-# (same prototype, same in[i] = i+1 / out[i] = 0 convention); unlike the reference script this one ASSERTS.
+# here steps 1-3 are  neptune-opt --neptuneir-to-hip --emit=so .  The generated driver uses the same
+# prototype and the same in[i] = i+1 / out[i] = 0 convention; unlike the reference script this one ASSERTS.
 set -euo pipefail
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 NEPTUNE_OPT=${NEPTUNE_OPT:-$ROOT/neptune-pde-solver_amd/bin/neptune-opt}
@@ -17,30 +17,29 @@ echo "[1/4] Lower to HIP and build the kernel library"
 
 echo "[2/4] Generate tiny driver"
 cat > driver.cpp <<'CPP'
+// Host-memory caller of the lowered @entry.  A rank-1 memref argument arrives as five scalars
+// (allocated, aligned, offset, size, stride) and the result comes back as the descriptor struct:
+// the calling convention of the reference's lowered functions.
 #include <cstdint>
 #include <cstdio>
-#include <cstdlib>
-struct MemRef1D { void* allocated; void* aligned; int64_t offset; int64_t sizes[1]; int64_t strides[1]; };
-// prototype = the LLVM-dialect expansion of (memref<?xf64>, memref<?xf64>) -> memref<?xf64>: 10 args
-extern "C" MemRef1D entry(void* a_alloc, void* a_aligned, int64_t a_off, int64_t a_s0, int64_t a_st0,
-                          void* b_alloc, void* b_aligned, int64_t b_off, int64_t b_s0, int64_t b_st0);
+#include <vector>
+struct Desc1 { void* allocated; void* aligned; int64_t offset; int64_t sizes[1]; int64_t strides[1]; };
+extern "C" Desc1 entry(void*, void*, int64_t, int64_t, int64_t, void*, void*, int64_t, int64_t, int64_t);
 int main() {
-  const int64_t n = 16;
-  double* out = (double*)aligned_alloc(64, sizeof(double) * n);
-  double* rhs = (double*)aligned_alloc(64, sizeof(double) * n);
-  for (int i = 0; i < n; ++i) { out[i] = 0.0; rhs[i] = (double)(i + 1); }
-  MemRef1D r = entry(out, out, 0, n, 1, rhs, rhs, 0, n, 1);
-  std::printf("[driver] ret aligned=%p size=%ld stride=%ld off=%ld\n", r.aligned, (long)r.sizes[0], (long)r.strides[0], (long)r.offset);
-  double* x = (double*)r.aligned;
-  int bad = (r.aligned != (void*)out) || r.sizes[0] != n;          // entry returns its destination field
-  for (int i = 0; i < (int)r.sizes[0]; ++i) {
-    std::printf("x[%d]=%.6f\n", i, x[i]);
-    // Lap(u)[i] = 100 * ((u[i-1] - 2 u[i]) + u[i+1]) = 0 on the ramp u = i+1; ends are copy-through
-    const double want = (i == 0 || i == n - 1) ? (double)(i + 1) : 0.0;
-    if (x[i] != want) bad = 1;
+  constexpr int64_t kCells = 16;
+  std::vector<double> dst(kCells, 0.0), src(kCells);
+  for (int64_t c = 0; c < kCells; ++c) src[c] = double(c + 1);          // smoke convention: in[i] = i+1, out[i] = 0
+  const Desc1 got = entry(dst.data(), dst.data(), 0, kCells, 1, src.data(), src.data(), 0, kCells, 1);
+  bool ok = got.aligned == dst.data() && got.sizes[0] == kCells && got.strides[0] == 1 && got.offset == 0;
+  const double* x = static_cast<const double*>(got.aligned);
+  for (int64_t c = 0; c < got.sizes[0]; ++c) {
+    // 100 * ((u[c-1] - 2 u[c]) + u[c+1]) vanishes on a ramp; the two end cells are copy-through
+    const double expect = (c == 0 || c == kCells - 1) ? double(c + 1) : 0.0;
+    std::printf("x[%lld]=%.6f\n", (long long)c, x[c]);
+    ok = ok && x[c] == expect;
   }
-  std::puts(bad ? "SMOKE_FAIL" : "SMOKE_OK");
-  return bad;
+  std::puts(ok ? "SMOKE_OK" : "SMOKE_FAIL");
+  return ok ? 0 : 1;
 }
 CPP
 
