@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--no-autotune", action="store_true",
                     help="skip the plan-time tuning (untimed, before warm-up) and use the library's default tile")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos before the interior (debug)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="diagnostic: run the multi-rank code path with every rank on cuda:0 and gloo as transport "
+                         "(halos staged through host memory); checks the control flow, not the speed")
     ap.add_argument("--emulate-rank", default="",
                     help="diagnostic, single process: 'R/W' runs the compute launches rank R of W would issue "
                          "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
@@ -138,6 +141,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device visible; the NeptuneIR HIP backend has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from neptune_hip import _capi, apply as nh_apply, fields, slab as slab_mod
@@ -146,7 +151,11 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"   # device of the few control tensors
 
     body_name, gshape, esize, points = WORKLOADS[args.workload]
     body = nh_apply.BODY_BY_NAME[body_name]
@@ -228,7 +237,7 @@ def main():
         n_ramp += 10
         go = time.perf_counter() - t_ramp < 0.3 and n_ramp < 2000
         if world > 1:   # every rank must run the same number of steps (each step is an exchange): rank 0 decides
-            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+            flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=coll_dev)
             dist.broadcast(flag, 0)
             go = bool(int(flag.item()))
         if not go:
@@ -257,7 +266,7 @@ def main():
     ev_ms = lib.neptune_hip_event_elapsed_ms(ev0, ev1)
 
     if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, ev_ms = float(t[0]), float(t[1])
 

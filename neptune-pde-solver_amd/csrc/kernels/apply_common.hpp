@@ -46,20 +46,32 @@ __host__ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // ---- footprint ------------------------------------------------------------------------
-// HALO_INPUT : index of the single input read at non-zero offsets, or -1 if every access is
-//              at offset 0 (a pointwise apply).  Bodies that read several inputs at non-zero
-//              offsets set MARCH_OK = false and run on the direct kernel.
-// R0,R1,R2   : max |offset| of that input along the march (I), row (J) and contiguous (K)
+// HALO_INPUT : index of the (lowest) input read at non-zero offsets, or -1 if every access is
+//              at offset 0 (a pointwise apply); HALO_MASK has one bit per such input.
+// R0,R1,R2   : max |offset| of the halo inputs along the march (I), row (J) and contiguous (K)
 //              axes *after* the rank mapping below.
 // BOX        : true if some access has more than one non-zero offset component (27-point);
 //              false for star stencils (5/7-point), which need no corner data.
-template <int HALO_INPUT_, int R0_, int R1_, int R2_, bool BOX_, bool MARCH_OK_ = true>
+template <int HALO_INPUT_, int R0_, int R1_, int R2_, bool BOX_, bool MARCH_OK_ = true,
+          unsigned HALO_MASK_ = (HALO_INPUT_ >= 0 ? (1u << (HALO_INPUT_ < 0 ? 0 : HALO_INPUT_)) : 0u)>
 struct Footprint {
-  static constexpr int HALO_INPUT = HALO_INPUT_;
+  static constexpr int HALO_INPUT = HALO_INPUT_;  // lowest halo input (or -1); kept for readability
+  // bit k set: input k is read at non-zero offsets and gets a register ring of its own.  Several
+  // halo inputs (e.g. the h and q fields of a shallow-water residual) share the radii below.
+  static constexpr unsigned HALO_MASK = HALO_MASK_;
   static constexpr int R0 = R0_, R1 = R1_, R2 = R2_;
   static constexpr bool BOX = BOX_;
   static constexpr bool MARCH_OK = MARCH_OK_;
 };
+constexpr int popcount_u(unsigned m) { int c = 0; for (; m; m &= m - 1) ++c; return c; }
+// index of input `in` among the set bits of `mask` (its ring slot)
+constexpr int halo_slot(unsigned mask, int in) { return popcount_u(mask & ((1u << in) - 1u)); }
+// input index of ring slot `h`
+constexpr int halo_input_of(unsigned mask, int h) {
+  for (int k = 0; k < 32; ++k)
+    if (mask & (1u << k)) { if (h == 0) return k; --h; }
+  return -1;
+}
 
 // Rank mapping onto the kernel's (I, J, K) axes.  K is always the contiguous last dim, I the
 // slowest.  rank 3: (d0,d1,d2) -> (I,J,K); rank 2: (d0,d1) -> (I,K), J has extent 1;

@@ -281,10 +281,15 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
     MarchParams<T, NIN> P{};
     for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
     P.out = static_cast<T*>(out);
-    // variant < 0 (or no cfg): automatic -- box stencils of rank 3 take their own default tile
+    // variant < 0 (or no cfg): automatic -- box stencils of rank 3 take their own default tile, and
+    // radius-2 stars or several halo inputs (more live rows per lane) the 2-row tile; in 2-D several
+    // halo inputs take the march form, whose state is one row per plane (the 4-row tile form spills
+    // from three halo inputs on).  Measured: tools/multihalo_bench.sh, profiles/r01_multihalo.txt.
     int variant = cfg ? cfg->variant : -1;
+    constexpr int kNH = popcount_u(FP::HALO_MASK);
+    constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
     if (variant < 0 || variant >= march_variant_count(RANK))
-      variant = (RANK == 3 && (FP::R0 > 1 || FP::R1 > 1)) ? 2 : (RANK == 3 && FP::BOX) ? 1 : 0;
+      variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 1) ? 1 : 0;
     // rank-2 tile form: (d0,d1) -> (J,K), one plane.  It cannot restrict rows (the march kernel's
     // region is a plane range), so a row-restricted launch takes the default march form.
     bool jk = RANK == 2 && march_variant(RANK, variant)->jk;

@@ -106,15 +106,17 @@ __device__ __forceinline__ T scalar_load(const T* p) {
 template <class T, int RANK, int NIN, class FP, int RJ, int r, int e, bool JK = false>
 struct MarchAcc {
   static constexpr int VK = 16 / sizeof(T);
-  static constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  static constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2;
+  static constexpr unsigned HMASK = FP::HALO_MASK;
+  static constexpr int NH = popcount_u(HMASK), NHX = NH ? NH : 1;
   static constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
   // K neighbours exist for every live plane (box) or for the centre plane only (star)
   static constexpr int NPH = FP::BOX ? NP : 1;
   using V = typename Vec16<T>::type;
 
-  const V (&ring)[NP][NR];
-  const T (&lft)[NPH][NR][NS];
-  const T (&rgt)[NPH][NR][NS];
+  const V (&ring)[NHX][NP][NR];
+  const T (&lft)[NHX][NPH][NR][NS];
+  const T (&rgt)[NHX][NPH][NR][NS];
   const V (&pt)[NIN][RJ];
   int64_t li, lj, lk;  // logical coordinates along (I,J,K)
 
@@ -124,18 +126,19 @@ struct MarchAcc {
     constexpr int oi = JK ? 0 : PickOffset<RANK, AxisMap<RANK>::I, O...>::value;
     constexpr int oj = JK ? PickOffset<RANK, 0, O...>::value : PickOffset<RANK, AxisMap<RANK>::J, O...>::value;
     constexpr int ok = PickOffset<RANK, AxisMap<RANK>::K, O...>::value;
-    if constexpr (IN == HIN) {
+    if constexpr ((HMASK >> IN) & 1u) {
+      constexpr int h = halo_slot(HMASK, IN);
       static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2,
                     "access outside the declared footprint");
       static_assert(FP::BOX || ((oi != 0) + (oj != 0) + (ok != 0) <= 1),
                     "star footprint declared but a diagonal access is used");
       constexpr int p = oi + R0, s = r + R1 + oj, ke = e + ok;
       constexpr int ph = FP::BOX ? p : 0;
-      if constexpr (ke < 0) return lft[ph][s][R2 + ke];
-      else if constexpr (ke >= VK) return rgt[ph][s][ke - VK];
-      else return ring[p][s][ke];
+      if constexpr (ke < 0) return lft[h][ph][s][R2 + ke];
+      else if constexpr (ke >= VK) return rgt[h][ph][s][ke - VK];
+      else return ring[h][p][s][ke];
     } else {
-      static_assert(oi == 0 && oj == 0 && ok == 0, "only the halo input may be read at an offset");
+      static_assert(oi == 0 && oj == 0 && ok == 0, "only halo inputs may be read at an offset");
       return pt[IN][r][e];
     }
   }
@@ -183,9 +186,11 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
   constexpr bool JK = RANK == 2 && TL::JK2;
-  constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2, HIN = FP::HALO_INPUT;
+  constexpr int R0 = JK ? 0 : FP::R0, R1 = JK ? FP::R0 : FP::R1, R2 = FP::R2;
+  constexpr unsigned HMASK = FP::HALO_MASK;
+  constexpr int NH = popcount_u(HMASK), NHX = NH ? NH : 1;  // halo inputs, each with its own ring
   constexpr bool BOX = FP::BOX;
-  constexpr bool HAS_HALO = HIN >= 0;
+  constexpr bool HAS_HALO = NH > 0;
   constexpr int NP = 2 * R0 + 1, NR = RJ + 2 * R1, NS = R2 ? R2 : 1;
   // Scalar K halos: a box stencil needs them for every live plane, so they travel with the
   // plane through the ring (fetched R0+1 steps ahead).  A star stencil needs them for the
@@ -208,8 +213,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // one neighbour can serve
   constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && R1 <= RJ && HAS_HALO;
   constexpr int LROWS = LDSJ ? 2 * R1 : 1;
-  // [double buffer][wave][first R1 own rows | last R1 own rows][lane]: 1 KiB per row
-  __shared__ V lds_rows[LDSJ ? 2 : 1][LDSJ ? WJ * WK : 1][LROWS][LDSJ ? kWave : 1];
+  // [double buffer][halo input][wave][first R1 own rows | last R1 own rows][lane]: 1 KiB per row
+  __shared__ V lds_rows[LDSJ ? 2 : 1][LDSJ ? NHX : 1][LDSJ ? WJ * WK : 1][LROWS][LDSJ ? kWave : 1];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -261,12 +266,12 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   });
 
   // ---- register state ----
-  V ring[NP][NR];           // live planes of the halo input (row vectors)
-  T khl[NPH][NR][NS];       // scalar K halos, left  (wave-uniform)
-  T khr[NPH][NR][NS];       // scalar K halos, right
-  V nxt[PF][NR];            // planes in flight (slot ph is consumed by steps i == ph mod PF)
-  V njh[PF][NJH];           // star stencils: J halo rows of the next PF centre planes, in flight
-  T nkhl[NR][NS], nkhr[NR][NS];
+  V ring[NHX][NP][NR];      // live planes of each halo input (row vectors)
+  T khl[NHX][NPH][NR][NS];  // scalar K halos, left  (wave-uniform)
+  T khr[NHX][NPH][NR][NS];  // scalar K halos, right
+  V nxt[NHX][PF][NR];       // planes in flight (slot ph is consumed by steps i == ph mod PF)
+  V njh[NHX][PF][NJH];      // star stencils: J halo rows of the next PF centre planes, in flight
+  T nkhl[NHX][NR][NS], nkhr[NHX][NR][NS];
   V pt[NIN][RJ];            // inputs read at offset 0 only, current plane
   V npt[NIN][RJ];           // ... next plane, in flight
 
@@ -279,10 +284,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   };
   // all_rows = true: fetch the J-halo rows from global memory too (prologue planes, which do
   // not pass through the LDS exchange)
-  auto load_rows = [&](int32_t ip, V(&rows)[NR], auto all_rows_c) {
+  auto load_rows = [&](auto hc, int32_t ip, V(&rows)[NR], auto all_rows_c) {
     constexpr bool all_rows = decltype(all_rows_c)::value;
     if constexpr (HAS_HALO) {
-      const char* base = plane_base(P.in[HIN], ip);
+      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
         auto ld = [&] {
@@ -305,9 +310,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   };
   // star stencils: the 2*R1 J-halo rows of plane ip (x < R1: rows above the tile, else below).  With
   // the LDS exchange only the workgroup's outermost waves need them from global memory.
-  auto load_jhalo = [&](int32_t ip, V(&jh)[NJH]) {
+  auto load_jhalo = [&](auto hc, int32_t ip, V(&jh)[NJH]) {
     if constexpr (JH_LATE && HAS_HALO) {
-      const char* base = plane_base(P.in[HIN], ip);
+      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
       static_for<2 * R1>([&](auto xc) {
         constexpr int x = xc;
         constexpr int s = x < R1 ? x : RJ + x;  // ring slot of that row (R1 + RJ + (x - R1))
@@ -320,9 +325,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
       });
     }
   };
-  auto load_khalos = [&](int32_t ip, T(&hl)[NR][NS], T(&hr)[NR][NS]) {
+  auto load_khalos = [&](auto hc, int32_t ip, T(&hl)[NR][NS], T(&hr)[NR][NS]) {
     if constexpr (HAS_HALO && R2 > 0) {
-      const char* base = plane_base(P.in[HIN], ip);
+      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
         if constexpr (need_khalo(s)) {
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   auto load_point_inputs = [&](int32_t ip, V(&dst)[NIN][RJ]) {
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
-      if constexpr (n != HIN) {
+      if constexpr (!((HMASK >> n) & 1u)) {
         const char* base = plane_base(P.in[n], ip);
         static_for<RJ>([&](auto rc) {
           constexpr int r = rc;
@@ -361,19 +366,22 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   });
 
   // ---- prologue: planes ib-R0 .. ib+R0-1 into ring[1..NP-1]; planes ib+R0 .. ib+R0+PF-1 in flight
-  static_for<NP - 1>([&](auto pc) {
-    constexpr int p = pc;
-    load_rows(ib - R0 + p, ring[p + 1], std::true_type{});  // shifted down at the top of the first step
-    if constexpr (BOX) load_khalos(ib - R0 + p, khl[p + 1], khr[p + 1]);
-  });
-  static_for<PF>([&](auto dc) {
-    constexpr int d = dc;
-    load_rows(ib + R0 + d, nxt[d], std::false_type{});
-  });
-  load_khalos(ib + HLEAD, nkhl, nkhr);
-  static_for<PF>([&](auto dc) {
-    constexpr int d = dc;
-    load_jhalo(ib + d, njh[d]);
+  static_for<NH>([&](auto hc) {
+    constexpr int h = hc;
+    static_for<NP - 1>([&](auto pc) {
+      constexpr int p = pc;
+      load_rows(hc, ib - R0 + p, ring[h][p + 1], std::true_type{});  // shifted down at the top of the first step
+      if constexpr (BOX) load_khalos(hc, ib - R0 + p, khl[h][p + 1], khr[h][p + 1]);
+    });
+    static_for<PF>([&](auto dc) {
+      constexpr int d = dc;
+      load_rows(hc, ib + R0 + d, nxt[h][d], std::false_type{});
+    });
+    load_khalos(hc, ib + HLEAD, nkhl[h], nkhr[h]);
+    static_for<PF>([&](auto dc) {
+      constexpr int d = dc;
+      load_jhalo(hc, ib + d, njh[h][d]);
+    });
   });
   load_point_inputs(ib, npt);
 
@@ -382,53 +390,62 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   auto step = [&](const int32_t i, auto slot_c) {
     constexpr int slot = slot_c;
     // rotate: ring[p] <- ring[p+1], newest plane <- nxt[slot]
-    static_for<NP - 1>([&](auto pc) {
-      constexpr int p = pc;
+    static_for<NH>([&](auto hc) {
+      constexpr int h = hc;
+      static_for<NP - 1>([&](auto pc) {
+        constexpr int p = pc;
+        static_for<NR>([&](auto sc) {
+          constexpr int s = sc;
+          if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[h][p][s] = ring[h][p + 1][s];
+          if constexpr (BOX) {
+            static_for<NS>([&](auto xc) {
+              constexpr int x = xc;
+              khl[h][p][s][x] = khl[h][p + 1][s][x];
+              khr[h][p][s][x] = khr[h][p + 1][s][x];
+            });
+          }
+        });
+      });
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
-        if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[p][s] = ring[p + 1][s];
-        if constexpr (BOX) {
-          static_for<NS>([&](auto xc) {
-            constexpr int x = xc;
-            khl[p][s][x] = khl[p + 1][s][x];
-            khr[p][s][x] = khr[p + 1][s][x];
-          });
-        }
+        if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[h][NP - 1][s] = nxt[h][slot][s];
+        static_for<NS>([&](auto xc) {
+          constexpr int x = xc;
+          khl[h][NPH - 1][s][x] = nkhl[h][s][x];
+          khr[h][NPH - 1][s][x] = nkhr[h][s][x];
+        });
       });
+      if constexpr (JH_LATE) {
+        // star: the centre plane's halo rows, fetched from global memory PF steps ago (by all waves
+        // without the LDS exchange, by the workgroup's outermost waves with it)
+        static_for<2 * R1>([&](auto xc) {
+          constexpr int x = xc;
+          ring[h][PJ][x < R1 ? x : RJ + x] = njh[h][slot][x];
+        });
+      }
     });
-    static_for<NR>([&](auto sc) {
-      constexpr int s = sc;
-      if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[NP - 1][s] = nxt[slot][s];
-      static_for<NS>([&](auto xc) {
-        constexpr int x = xc;
-        khl[NPH - 1][s][x] = nkhl[s][x];
-        khr[NPH - 1][s][x] = nkhr[s][x];
-      });
-    });
-    if constexpr (JH_LATE) {
-      // star: the centre plane's halo rows, fetched from global memory PF steps ago (by all waves
-      // without the LDS exchange, by the workgroup's outermost waves with it)
-      static_for<2 * R1>([&](auto xc) {
-        constexpr int x = xc;
-        ring[PJ][x < R1 ? x : RJ + x] = njh[slot][x];
-      });
-    }
     if constexpr (LDSJ) {
       // J-halo rows of plane PJ (box: the plane that just arrived; star: the plane that just became
-      // the centre): publish my first/last R1 own rows, take the neighbouring waves' rows.
-      // Double-buffered by step parity, one barrier per step.
+      // the centre), for every halo input: publish my first/last R1 own rows, take the neighbouring
+      // waves' rows.  Double-buffered by step parity, ONE barrier per step.
       const int buf = (i - ib) & 1;
-      static_for<R1>([&](auto xc) {
-        constexpr int x = xc;
-        lds_rows[buf][w][x][lane] = ring[PJ][R1 + x];            // first own rows
-        lds_rows[buf][w][R1 + x][lane] = ring[PJ][RJ + x];       // last own rows (s = R1+RJ-R1+x)
+      static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        static_for<R1>([&](auto xc) {
+          constexpr int x = xc;
+          lds_rows[buf][h][w][x][lane] = ring[h][PJ][R1 + x];            // first own rows
+          lds_rows[buf][h][w][R1 + x][lane] = ring[h][PJ][RJ + x];       // last own rows (s = R1+RJ-R1+x)
+        });
       });
       __syncthreads();
-      static_for<R1>([&](auto xc) {
-        constexpr int x = xc;
-        // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
-        if (wj > 0) ring[PJ][x] = lds_rows[buf][w - WK][R1 + x][lane];
-        if (wj < WJ - 1) ring[PJ][R1 + RJ + x] = lds_rows[buf][w + WK][x][lane];
+      static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        static_for<R1>([&](auto xc) {
+          constexpr int x = xc;
+          // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
+          if (wj > 0) ring[h][PJ][x] = lds_rows[buf][h][w - WK][R1 + x][lane];
+          if (wj < WJ - 1) ring[h][PJ][R1 + RJ + x] = lds_rows[buf][h][w + WK][x][lane];
+        });
       });
     }
     static_for<NIN>([&](auto nc) {
@@ -437,29 +454,35 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     });
     // refill the slot just consumed with the plane PF steps ahead; K halos and offset-0 inputs
     // are one step ahead
-    if (i + PF < ie) load_rows(i + PF + R0, nxt[slot], std::false_type{});
-    if (i + PF < ie) load_jhalo(i + PF, njh[slot]);  // the plane that is the centre PF steps from now
-    if (i + 1 < ie) {
-      load_khalos(i + 1 + HLEAD, nkhl, nkhr);
-      load_point_inputs(i + 1, npt);
-    }
+    static_for<NH>([&](auto hc) {
+      constexpr int h = hc;
+      if (i + PF < ie) {
+        load_rows(hc, i + PF + R0, nxt[h][slot], std::false_type{});
+        load_jhalo(hc, i + PF, njh[h][slot]);  // the plane that is the centre PF steps from now
+      }
+      if (i + 1 < ie) load_khalos(hc, i + 1 + HLEAD, nkhl[h], nkhr[h]);
+    });
+    if (i + 1 < ie) load_point_inputs(i + 1, npt);
 
     // K neighbours from adjacent lanes (edges from the scalar halos)
-    T lft[NPH][NR][NS], rgt[NPH][NR][NS];
+    T lft[NHX][NPH][NR][NS], rgt[NHX][NPH][NR][NS];
     if constexpr (R2 > 0) {
-      static_for<NPH>([&](auto pc) {
-        constexpr int ph = pc;
-        constexpr int p = BOX ? ph : R0;  // star: centre plane only
-        static_for<NR>([&](auto sc) {
-          constexpr int s = sc;
-          // star stencils read K neighbours only on own rows
-          if constexpr (BOX || (s >= R1 && s < R1 + RJ)) {
-            static_for<R2>([&](auto xc) {
-              constexpr int x = xc;
-              lft[ph][s][x] = from_prev<DPP>(ring[p][s][VK - R2 + x], khl[ph][s][x], lane);
-              rgt[ph][s][x] = from_next<DPP>(ring[p][s][x], khr[ph][s][x], lane);
-            });
-          }
+      static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        static_for<NPH>([&](auto pc) {
+          constexpr int ph = pc;
+          constexpr int p = BOX ? ph : R0;  // star: centre plane only
+          static_for<NR>([&](auto sc) {
+            constexpr int s = sc;
+            // star stencils read K neighbours only on own rows
+            if constexpr (BOX || (s >= R1 && s < R1 + RJ)) {
+              static_for<R2>([&](auto xc) {
+                constexpr int x = xc;
+                lft[h][ph][s][x] = from_prev<DPP>(ring[h][p][s][VK - R2 + x], khl[h][ph][s][x], lane);
+                rgt[h][ph][s][x] = from_next<DPP>(ring[h][p][s][x], khr[h][ph][s][x], lane);
+              });
+            }
+          });
         });
       });
     }
@@ -479,7 +502,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         MarchAcc<T, RANK, NIN, FP, RJ, r, e, JK> acc{ring, lft, rgt, pt, li, lj, lk};
         const T val = body(acc);
         T through;  // copy-through source: input 0 at the same physical index
-        if constexpr (HIN == 0) through = ring[R0][r + R1][e];
+        if constexpr (HMASK & 1u) through = ring[0][R0][r + R1][e];  // input 0 owns ring slot 0
         else through = pt[0][r][e];
         res[e] = inside ? val : through;
       });

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <functional>
 #include <set>
+#include <algorithm>
 #include <sstream>
 
 #include "lowering.h"
@@ -248,26 +249,34 @@ struct Emitter {
     // inputs never read unconditionally keep top_radius -1 ("not accessed": nothing to check)
     scan_accesses(blk, temp_index, fp, true);
     // rank mapping onto the kernel's (I,J,K) axes, see apply_common.hpp AxisMap
+    // every input read at a non-zero offset gets a register ring in the march kernel; the rings share
+    // the largest radii
     int halo_inputs = 0;
+    unsigned halo_mask = 0;
+    int R[3] = {0, 0, 0};
     for (int k = 0; k < nin; ++k) {
       bool any = false;
       for (int d = 0; d < rank; ++d) any = any || fp.radius[k][d] > 0;
-      if (any) { ++halo_inputs; fp.halo_input = k; }
-    }
-    int R[3] = {0, 0, 0};
-    if (fp.halo_input >= 0) {
-      const int* r = fp.radius[fp.halo_input];
-      if (rank == 3) { R[0] = r[0]; R[1] = r[1]; R[2] = r[2]; }
-      else if (rank == 2) { R[0] = r[0]; R[2] = r[1]; }
-      else { R[2] = r[0]; }
+      if (!any) continue;
+      ++halo_inputs;
+      halo_mask |= 1u << k;
+      if (fp.halo_input < 0) fp.halo_input = k;
+      const int* r = fp.radius[k];
+      int m[3] = {0, 0, 0};
+      if (rank == 3) { m[0] = r[0]; m[1] = r[1]; m[2] = r[2]; }
+      else if (rank == 2) { m[0] = r[0]; m[2] = r[1]; }
+      else { m[2] = r[0]; }
+      for (int a = 0; a < 3; ++a) R[a] = std::max(R[a], m[a]);
     }
     const int vk = 16 / esize(res.elem);
-    // the march kernel keeps 2*R0+1 planes of RJ+2*R1 rows in registers: radius 1 for box stencils,
-    // up to 2 for star stencils (4th-order 13-point operators); wider footprints use the direct kernel
+    // the march kernel keeps 2*R0+1 planes of RJ+2*R1 rows per halo input in registers: radius 1 for
+    // box stencils, up to 2 for star stencils (4th-order 13-point operators), and at most two halo
+    // inputs in 3-D (all four in 1-D/2-D, where a plane is one row); wider footprints use the direct
+    // kernel
     const int rmax = fp.box ? 1 : 2;
-    fp.march_ok = halo_inputs <= 1 && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
-    if (halo_inputs > 1) fp.halo_input = -1, R[0] = R[1] = R[2] = 0;
-    if (!fp.march_ok) { fp.halo_input = halo_inputs == 1 ? fp.halo_input : -1; }
+    const int hmax = rank == 3 ? ((R[0] > 1 || R[1] > 1) ? 1 : 2) : 4;
+    fp.march_ok = halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
+    if (!fp.march_ok) { fp.halo_input = -1; halo_mask = 0; R[0] = R[1] = R[2] = 0; }
 
     std::ostringstream& o = bodies;
     o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
@@ -275,9 +284,10 @@ struct Emitter {
     o << "  template <class A>\n  __device__ __forceinline__ " << ctype(res.elem) << " operator()(const A& a) const {\n";
     if (!emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr)) return false;
     o << "  }\n};\n";
-    o << "using FP_" << tag << " = neptune_hip::Footprint<" << (fp.march_ok ? fp.halo_input : -1) << ", "
-      << (fp.march_ok ? R[0] : 0) << ", " << (fp.march_ok ? R[1] : 0) << ", " << (fp.march_ok ? R[2] : 0) << ", "
-      << ((fp.box && fp.march_ok) ? "true" : "false") << ", " << (fp.march_ok ? "true" : "false") << ">;\n";
+    o << "using FP_" << tag << " = neptune_hip::Footprint<" << fp.halo_input << ", " << R[0] << ", " << R[1] << ", " << R[2] << ", "
+      << ((fp.box && fp.march_ok) ? "true" : "false") << ", " << (fp.march_ok ? "true" : "false");
+    if (halo_inputs > 1 && fp.march_ok) o << ", 0x" << std::hex << halo_mask << std::dec << "u";
+    o << ">;\n";
     o << "static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
     for (int k = 0; k < 4; ++k) {
       o << (k ? ", {" : "{");

@@ -230,6 +230,25 @@ inline void fill_geom(neptune_hip_apply_geom_t& g, const Box& out, const Box& bo
 // `top_radius`: max |offset| of the UNCONDITIONAL accesses (those not nested under scf.if) -- the
 // ones that certainly execute for every in-bounds point and must therefore stay inside their
 // input's box (out of bounds = undefined behaviour in the reference, rejected here).
+// Tuning/testing override for every apply of a lowered module, read at each launch:
+//   NEPTUNE_HIP_KERNEL=direct|march   NEPTUNE_HIP_VARIANT=<tile index>   NEPTUNE_HIP_CHUNK=<planes>
+// A forced march kernel that cannot take the launch (narrow or unaligned rows) is an error, as in
+// neptune_hip_apply_builtin.  Unset: the automatic choice.
+inline const neptune_hip_launch_cfg_t* launch_override() {
+  static thread_local neptune_hip_launch_cfg_t cfg;
+  const char* k = getenv("NEPTUNE_HIP_KERNEL");
+  const char* v = getenv("NEPTUNE_HIP_VARIANT");
+  const char* c = getenv("NEPTUNE_HIP_CHUNK");
+  if (!k && !v && !c) return nullptr;
+  cfg.kernel = !k ? NEPTUNE_HIP_KERNEL_AUTO
+                  : (!strcmp(k, "direct") ? NEPTUNE_HIP_KERNEL_DIRECT
+                                          : (!strcmp(k, "march") ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_KERNEL_AUTO));
+  cfg.variant = v ? atoi(v) : -1;
+  cfg.chunk = c ? atoi(c) : 0;
+  cfg.flags = 0;
+  return &cfg;
+}
+
 template <class Body, class T, int RANK, int NIN, class FP>
 inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const Box& bounds, const Val* const* in,
                      const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest) {
@@ -251,7 +270,7 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const B
   }
   const void* ptrs[NIN];
   for (int k = 0; k < NIN; ++k) ptrs[k] = in[k]->dev;
-  rc = launch_apply<Body, T, RANK, NIN, FP>(body, &g, ptrs, out.dev, sc.stream(), nullptr);
+  rc = launch_apply<Body, T, RANK, NIN, FP>(body, &g, ptrs, out.dev, sc.stream(), launch_override());
   if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
   if (direct) sc.mark_dirty(*dest);
   return out;

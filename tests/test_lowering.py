@@ -214,3 +214,20 @@ def test_explicit_time_advance_lowers_and_implicit_stays_on_the_host():
     assert rep2["lowered"] == ["lap"] and rep2["skipped"][0]["symbol"] == "step"
     with pytest.raises(lowering.LoweringError, match="rhs must reference linear_opdef or nonlinear_opdef"):
         lowering.verify(text.replace("rhs = @lap", "rhs = @nope"))
+
+
+def test_several_halo_inputs_get_a_mask_and_shared_radii():
+    """inputs 1 and 2 read at offsets, input 0 only at the centre: Footprint<first halo input, shared radii..., mask>;
+    radius 2 with two halo inputs in 3-D is left to the direct kernel"""
+    import test_multihalo_gpu as mh
+    shape, elem, nin, accesses, _, _ = mh.CASES["point0_then_two_stars"]
+    src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [1, 1, 1], [n - 1 for n in shape]))
+    assert "neptune_hip::Footprint<1, 1, 1, 1, false, true, 0x6u>" in src
+    assert rep["applies"][0]["kernel"] == "march"
+    shape, elem, nin, accesses, _, _ = mh.CASES["radius2_pair_3d"]
+    src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [2, 2, 2], [n - 2 for n in shape]))
+    assert "neptune_hip::Footprint<-1, 0, 0, 0, false, false>" in src
+    assert rep["applies"][0]["kernel"] == "direct"
+    shape, elem, nin, accesses, _, _ = mh.CASES["four_halo_inputs_2d"]
+    src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [1, 1], [n - 1 for n in shape]))
+    assert "neptune_hip::Footprint<0, 1, 0, 1, false, true, 0xfu>" in src

@@ -1,0 +1,158 @@
+"""Applies that read SEVERAL inputs at non-zero offsets (the shape of the reference's shallow-water
+residuals: h and q both at +-1) on the march kernel: one register ring per halo input, shared radii,
+one LDS exchange and barrier per plane step.  Every case is lowered from NeptuneIR text and compared
+bit for bit with the oracle; NEPTUNE_HIP_VARIANT / NEPTUNE_HIP_CHUNK force each default tile and put
+chunk seams inside the field."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import bits_equal, mismatch_report, oracle
+
+pytestmark = pytest.mark.gpu
+
+# exactly representable, all different, so a swapped operand or ring slot changes bits
+COEF = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 0.0625, -3.0, 1.75, 0.3125, -0.4375, 2.5, -0.1875, 0.875,
+        1.125, -2.25, 0.6875, -0.5625, 3.5, -1.375, 0.21875, 0.9375, -1.625, 2.75, -0.3125, 1.0625]
+
+
+def module_text(shape, elem, nin, accesses, lb, ub):
+    """one nonlinear_opdef @resid holding one apply; the body is sum_i COEF[i] * access_i evaluated left to
+    right, plus an index-dependent term so a shifted tile origin is visible"""
+    rank = len(shape)
+    dims = "x".join("?" * rank)
+    zeros = ", ".join("0" * rank)
+    ubs = ", ".join(str(n) for n in shape)
+    tys = ", ".join(["!t"] * nin)
+    idx = ", ".join(f"%i{d}: index" for d in range(rank))
+    ins = ", ".join(f"%a{k}: !t" for k in range(nin))
+    L = [f'#l = #neptune_ir.location<"cell">',
+         f"#b = #neptune_ir.bounds<lb = [{zeros}], ub = [{ubs}]>",
+         f"!t = !neptune_ir.temp<element = {elem}, bounds = #b, location = #l>",
+         f"!f = !neptune_ir.field<element = {elem}, bounds = #b, location = #l>",
+         "module {",
+         f"  neptune_ir.nonlinear_opdef @resid : ({tys}) -> !t {{",
+         "  ^bb0(" + ", ".join(f"%u{k}: !t" for k in range(nin)) + "):",
+         "    %r = neptune_ir.apply(" + ", ".join(f"%u{k}" for k in range(nin)) + ") attributes {bounds = "
+         f"#neptune_ir.bounds<lb = [{', '.join(map(str, lb))}], ub = [{', '.join(map(str, ub))}]>}} : ({tys}) -> !t {{",
+         f"      ^bb0({idx}, {ins}):"]
+    for i, (k, off) in enumerate(accesses):
+        L.append(f"        %v{i} = neptune_ir.access %a{k}[{', '.join(map(str, off))}] : !t -> {elem}")
+    for i in range(len(accesses)):
+        L.append(f"        %c{i} = arith.constant {COEF[i]!r} : {elem}")
+        L.append(f"        %m{i} = arith.mulf %c{i}, %v{i} : {elem}")
+        if i == 0:
+            L.append(f"        %s0 = arith.addf %m0, %m0 : {elem}")
+        else:
+            L.append(f"        %s{i} = arith.addf %s{i - 1}, %m{i} : {elem}")
+    n = len(accesses) - 1
+    last = f"%i{rank - 1}"
+    L += [f"        %w = arith.index_cast {last} : index to i64",
+          f"        %wf = arith.sitofp %w : i64 to {elem}",
+          f"        %o = arith.addf %s{n}, %wf : {elem}",
+          f"        neptune_ir.yield %o : {elem}",
+          "    }",
+          "    neptune_ir.return %r : !t",
+          "  }",
+          f"  func.func @entry(%out: memref<{dims}x{elem}>, " + ", ".join(f"%in{k}: memref<{dims}x{elem}>" for k in range(nin))
+          + f") -> memref<{dims}x{elem}> {{",
+          f"    %fo = neptune_ir.wrap %out : memref<{dims}x{elem}> -> !f"]
+    for k in range(nin):
+        L.append(f"    %f{k} = neptune_ir.wrap %in{k} : memref<{dims}x{elem}> -> !f")
+        L.append(f"    %t{k} = neptune_ir.load %f{k} : !f -> !t")
+    L += ["    %y = neptune_ir.apply_nonlinear @resid(" + ", ".join(f"%t{k}" for k in range(nin)) + f") : ({tys}) -> !t",
+          "    neptune_ir.store %y to %fo : !t to !f",
+          f"    %res = neptune_ir.unwrap %fo : !f -> memref<{dims}x{elem}>",
+          f"    func.return %res : memref<{dims}x{elem}>",
+          "  }", "}"]
+    return "\n".join(L) + "\n"
+
+
+def star(rank, r=1):
+    out = [tuple([0] * rank)]
+    for d in range(rank):
+        for s in range(1, r + 1):
+            for sign in (-1, 1):
+                o = [0] * rank
+                o[d] = sign * s
+                out.append(tuple(o))
+    return out
+
+
+CASES = {
+    # name: (shape, elem, nin, accesses, bounds margin, expected kernel)
+    "swe3d_two_stars": ((13, 19, 256), "f64", 2, [(0, o) for o in star(3)] + [(1, o) for o in star(3)], 1, "march"),
+    "point0_then_two_stars": ((11, 10, 128), "f64", 3,
+                              [(0, (0, 0, 0))] + [(1, o) for o in star(3)] + [(2, o) for o in star(3)[1:]], 1, "march"),
+    "unequal_radii": ((9, 12, 128), "f64", 2,
+                      [(0, (0, 0, 0)), (0, (-1, 0, 0)), (0, (1, 0, 0)), (1, (0, -1, 0)), (1, (0, 1, 0)), (1, (0, 0, 1)), (1, (0, 0, -1))],
+                      1, "march"),
+    "two_boxes_f32": ((10, 13, 256), "f32", 2,
+                      [(0, (0, 0, 0)), (0, (-1, -1, -1)), (0, (1, 1, 1)), (0, (1, -1, 0)), (1, (-1, 1, 1)), (1, (1, -1, -1)),
+                       (1, (0, 1, -1)), (1, (-1, 0, 1)), (1, (0, 0, 0))], 1, "march"),
+    "swe2d": ((40, 512), "f64", 2, [(0, o) for o in star(2)] + [(1, o) for o in star(2)], 1, "march"),
+    "four_halo_inputs_2d": ((24, 256), "f64", 4, [(k, o) for k in range(4) for o in star(2)], 1, "march"),
+    "radius2_pair_2d": ((30, 256), "f64", 2, [(0, o) for o in star(2, 2)] + [(1, o) for o in star(2, 2)[1:]], 2, "march"),
+    "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
+    "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
+    # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
+    "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "direct"),
+}
+
+
+@pytest.fixture(scope="module")
+def env(built_libs, tmp_path_factory):
+    import torch
+    assert torch.cuda.is_available()
+    os.environ["NEPTUNE_CACHE_DIR"] = str(tmp_path_factory.mktemp("neptune_cache_mh"))
+    from neptune_hip import lowering
+    return lowering, torch
+
+
+@pytest.fixture
+def launch_env():
+    saved = {k: os.environ.get(k) for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK")}
+    yield
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_several_halo_inputs_match_the_oracle(env, launch_env, name):
+    lowering, torch = env
+    shape, elem, nin, accesses, margin, kernel = CASES[name]
+    rank = len(shape)
+    dt = np.float64 if elem == "f64" else np.float32
+    lb = [margin] * rank
+    ub = [n - margin for n in shape]
+    if rank == 3:
+        lb[0], ub[1] = margin + 1, shape[1] - margin - 2      # bounds tighter than the halo margin: more copy-through
+    text = module_text(shape, elem, nin, accesses, lb, ub)
+    ins = [helpers.hash_field(shape, dt, seed=40 + k) for k in range(nin)]
+    want = np.full(shape, -7.0, dtype=dt)
+    oracle.Module.parse(text).call("entry", want, *ins)
+    mod = lowering.compile_module(text)
+    assert {a["function"]: a["kernel"] for a in mod.report["applies"]}["resid"] == kernel
+    d_ins = [torch.from_numpy(a).cuda() for a in ins]
+    tdt = torch.float64 if elem == "f64" else torch.float32
+    # automatic tile, then every default tile with chunk seams inside the field, then the direct kernel
+    settings = [{}]
+    if kernel == "march":
+        nvar = {3: 3, 2: 2, 1: 1}[rank]
+        settings += [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c} for v in range(nvar) for c in ("1", "4")]
+        settings += [{"NEPTUNE_HIP_KERNEL": "direct"}]
+    for s in settings:
+        for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
+            os.environ.pop(k, None)
+        os.environ.update(s)
+        d_out = torch.full(shape, -7.0, dtype=tdt, device="cuda")
+        mod.call("entry", d_out, *d_ins)
+        got = d_out.cpu().numpy()
+        assert bits_equal(got, want), f"{name} {s}: " + mismatch_report(got, want)
+    # outside the apply bounds the result is input 0, whichever ring or register it came from
+    assert bits_equal(want[0], ins[0][0])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time a lowered module's @entry(out, in) on device-resident fields.
+"""Time a lowered module's @entry(out, in...) on device-resident fields.
 usage: tools/time_module.py <file.mlir> [--reps N]      (field shape comes from the module's types)"""
 import argparse
 import json
@@ -28,17 +28,18 @@ def main():
     ub = [int(x) for x in m.group(2).split(",")]
     shape = [u - l for l, u in zip(lb, ub)]
     dt = torch.float64 if sig["args"][0]["elem"] == "f64" else torch.float32
-    a = torch.rand(shape, dtype=dt, device="cuda") * 2 - 1
+    nin = sum(1 for x in sig["args"] if x.get("kind", "memref") == "memref") - 1
+    ins = [torch.rand(shape, dtype=dt, device="cuda") * 2 - 1 for _ in range(nin)]
     b = torch.zeros(shape, dtype=dt, device="cuda")
     for _ in range(3):
-        mod.call(args.symbol, b, a)
+        mod.call(args.symbol, b, *ins)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.reps):
-        mod.call(args.symbol, b, a)          # each call synchronises at exit (ABI: results are ready)
+        mod.call(args.symbol, b, *ins)       # each call synchronises at exit (ABI: results are ready)
     torch.cuda.synchronize()
     dtm = (time.perf_counter() - t0) / args.reps
-    nbytes = 2 * a.numel() * a.element_size()
+    nbytes = (nin + 1) * b.numel() * b.element_size()   # every input read once, the result written once
     print(json.dumps({"module": args.mlir, "shape": shape, "ms_per_call": dtm * 1e3, "GBps": nbytes / dtm / 1e9,
                       "applies": mod.report["applies"]}))
 
