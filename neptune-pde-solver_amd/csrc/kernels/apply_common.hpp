@@ -73,6 +73,19 @@ constexpr int halo_input_of(unsigned mask, int h) {
   return -1;
 }
 
+// Value of a cell outside apply.bounds: input 0 at the same physical index (copy-through,
+// DataflowLowering.cpp:283-287), unless the body functor supplies `T outside(T through) const` --
+// the fused explicit time step does, because outside its rhs operator's bounds the rhs IS the
+// copy-through of the state and the axpy still applies there.
+template <class Body, class T, class = void>
+struct OutsideOf {
+  static __device__ __forceinline__ T apply(const Body&, T through) { return through; }
+};
+template <class Body, class T>
+struct OutsideOf<Body, T, std::void_t<decltype(std::declval<const Body&>().outside(std::declval<T>()))>> {
+  static __device__ __forceinline__ T apply(const Body& b, T through) { return b.outside(through); }
+};
+
 // Rank mapping onto the kernel's (I, J, K) axes.  K is always the contiguous last dim, I the
 // slowest.  rank 3: (d0,d1,d2) -> (I,J,K); rank 2: (d0,d1) -> (I,K), J has extent 1;
 // rank 1: (d0) -> (K), I and J have extent 1.

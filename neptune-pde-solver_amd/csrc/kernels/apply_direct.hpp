@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void neptune_apply_direct(DirectParams<T, NIN>
   }
   const T through = P.in[0][o];  // copy-through: physical-index-wise (DataflowLowering.cpp:283-287)
   const T val = body(acc);
-  P.out[o] = inside ? val : through;
+  P.out[o] = inside ? val : OutsideOf<Body, T>::apply(body, through);
 }
 
 }  // namespace neptune_hip

@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         T through;  // copy-through source: input 0 at the same physical index
         if constexpr (HMASK & 1u) through = ring[0][R0][r + R1][e];  // input 0 owns ring slot 0
         else through = pt[0][r][e];
-        res[e] = inside ? val : through;
+        res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
       if (row_ok[r] && lane_ok) {
         // rowb[r+R1] is this own row's offset (own rows are never clamped when row_ok)

@@ -55,5 +55,29 @@ struct EulerAxpy {
   }
 };
 
+// The same step in ONE pass over the state when the rhs opdef is a single apply of the state:
+// inside that apply's bounds k = Rhs(a); outside them the rhs result is its copy-through of the
+// state, so k = s (see OutsideOf in apply_common.hpp).  Same two roundings as EulerAxpy, hence the
+// same bits as the two-kernel form -- it only saves the round trip of k through HBM
+// (2 field passes instead of 5).
+template <class Rhs, class T, int RANK>
+struct EulerFused {
+  T dt;
+  template <class A>
+  __device__ __forceinline__ T operator()(const A& a) const {
+    const T k0 = Rhs{}(a);
+    T s0;
+    if constexpr (RANK == 1) s0 = a.template get<0, 0>();
+    else if constexpr (RANK == 2) s0 = a.template get<0, 0, 0>();
+    else s0 = a.template get<0, 0, 0, 0>();
+    const T dt_k = dt * k0;
+    return s0 + dt_k;
+  }
+  __device__ __forceinline__ T outside(T s0) const {
+    const T dt_k = dt * s0;
+    return s0 + dt_k;
+  }
+};
+
 }  // namespace ops
 }  // namespace neptune_hip

@@ -81,6 +81,9 @@ struct Footprint {
   int top_radius[4][3];  // unconditional accesses only; -1 = none
   bool box = false;
   int halo_input = -1;
+  unsigned halo_mask = 0;
+  int halo_inputs = 0;
+  int R[3] = {0, 0, 0};  // shared radii on the kernel's (I,J,K) axes
   bool march_ok = true;
 };
 
@@ -228,7 +231,10 @@ struct Emitter {
     return true;
   }
 
-  bool emit_body(const Op& apply, const std::string& tag, Footprint& fp) {
+  // checks + footprint of one apply (no emission): which inputs need a ring, the shared radii on the
+  // kernel's axes, whether the march kernel can take it
+  bool analyze_apply(const Op& apply, Footprint& fp, std::map<std::string, int>& temp_index,
+                     std::map<std::string, int>& index_arg) {
     const Block& blk = *apply.regions[0];
     const Bounds& b = apply.attrs.at("bounds").bounds;
     const int rank = b.rank();
@@ -239,27 +245,25 @@ struct Emitter {
     if (res.elem != "f64" && res.elem != "f32") { diag.fail(apply.line, "apply element type " + res.elem + " (f64 and f32 are supported)"); return false; }
     for (int k = 0; k < nin; ++k)
       if (apply.types[k].elem != res.elem) { diag.fail(apply.line, "apply inputs of mixed element types"); return false; }
+    fp = Footprint();
     fp.nin = nin;
     fp.rank = rank;
     for (int k = 0; k < 4; ++k)
       for (int d = 0; d < 3; ++d) { fp.radius[k][d] = 0; fp.top_radius[k][d] = -1; }
-    std::map<std::string, int> temp_index, index_arg;
     for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d;
     for (int k = 0; k < nin; ++k) temp_index[blk.args[rank + k].name] = k;
     // inputs never read unconditionally keep top_radius -1 ("not accessed": nothing to check)
     scan_accesses(blk, temp_index, fp, true);
-    // rank mapping onto the kernel's (I,J,K) axes, see apply_common.hpp AxisMap
+    // rank mapping onto the kernel's (I,J,K) axes, see apply_common.hpp AxisMap.
     // every input read at a non-zero offset gets a register ring in the march kernel; the rings share
     // the largest radii
-    int halo_inputs = 0;
-    unsigned halo_mask = 0;
-    int R[3] = {0, 0, 0};
+    int* R = fp.R;
     for (int k = 0; k < nin; ++k) {
       bool any = false;
       for (int d = 0; d < rank; ++d) any = any || fp.radius[k][d] > 0;
       if (!any) continue;
-      ++halo_inputs;
-      halo_mask |= 1u << k;
+      ++fp.halo_inputs;
+      fp.halo_mask |= 1u << k;
       if (fp.halo_input < 0) fp.halo_input = k;
       const int* r = fp.radius[k];
       int m[3] = {0, 0, 0};
@@ -275,8 +279,21 @@ struct Emitter {
     // kernel
     const int rmax = fp.box ? 1 : 2;
     const int hmax = rank == 3 ? ((R[0] > 1 || R[1] > 1) ? 1 : 2) : 4;
-    fp.march_ok = halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
-    if (!fp.march_ok) { fp.halo_input = -1; halo_mask = 0; R[0] = R[1] = R[2] = 0; }
+    fp.march_ok = fp.halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= rmax && R[2] <= vk;
+    if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }
+    return true;
+  }
+
+  bool emit_body(const Op& apply, const std::string& tag, Footprint& fp) {
+    const Block& blk = *apply.regions[0];
+    const int nin = (int)apply.operands.size();
+    const int rank = apply.attrs.at("bounds").bounds.rank();
+    const Type& res = apply.types[nin];
+    std::map<std::string, int> temp_index, index_arg;
+    if (!analyze_apply(apply, fp, temp_index, index_arg)) return false;
+    const int* R = fp.R;
+    const int halo_inputs = fp.halo_inputs;
+    const unsigned halo_mask = fp.halo_mask;
 
     std::ostringstream& o = bodies;
     o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
@@ -450,11 +467,59 @@ struct Emitter {
         else if ((int)oi == returned_producer) dest = "dest";
         const std::string tag = f.name + "_ta" + std::to_string(apply_counter++);
         const std::string bx = new_box(st.bounds);
+        const std::string T = ctype(st.elem);
+        // Fusable: the rhs opdef is exactly "apply(state) ; return" with result box == state box.  Then
+        // one kernel computes state + dt * rhs(state) (ops::EulerFused); anything else takes the
+        // two-kernel form below.  Both produce the same bits.
+        const Function* c = m.find(op.callee);
+        const Op* rhs_apply = nullptr;
+        if (c && c->arg_types.size() == 1 && c->body.ops.size() == 2 && c->body.ops[0]->name == "neptune_ir.apply" &&
+            c->body.ops[1]->name == "neptune_ir.return" && c->body.ops[1]->operands.size() == 1 &&
+            c->body.ops[1]->operands[0] == c->body.ops[0]->results.at(0) && c->body.ops[0]->operands.size() == 1 &&
+            c->body.ops[0]->operands[0] == c->body.args[0].name) {
+          const Op& a = *c->body.ops[0];
+          const Type& rt = a.types[1];
+          bool same = a.types[0].is_tempish() && rt.elem == st.elem && rt.bounds.rank() == st.rank() && a.types[0].elem == st.elem;
+          for (int d = 0; same && d < st.rank(); ++d)
+            same = rt.bounds.lb[d] == st.bounds.lb[d] && rt.bounds.ub[d] == st.bounds.ub[d] &&
+                   a.types[0].bounds.lb[d] == st.bounds.lb[d] && a.types[0].bounds.ub[d] == st.bounds.ub[d];
+          if (same) rhs_apply = &a;
+        }
+        if (rhs_apply) {
+          Footprint cfp;
+          std::map<std::string, int> ti, ia;
+          if (!analyze_apply(*rhs_apply, cfp, ti, ia)) return false;
+          const std::string ctag = op.callee + "_0";  // the tag emit_function gives the opdef's only apply
+          o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee
+            << "}: state + dt * rhs(state), rhs apply and axpy fused into one kernel\n";
+          o << "  static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
+          for (int k = 0; k < 4; ++k) {
+            o << (k ? ", {" : "{");
+            for (int d = 0; d < 3; ++d)
+              o << (d ? ", " : "") << (k == 0 && d < st.rank() ? std::max(cfp.top_radius[0][d], 0) : -1);  // the axpy reads the centre
+            o << "}";
+          }
+          o << "};\n";
+          o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << "};\n";
+          const std::string body = "neptune_hip::ops::EulerFused<Body_" + ctag + ", " + T + ", " + std::to_string(st.rank()) + ">";
+          o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<" << body << ", " << T << ", " << st.rank() << ", 1, FP_"
+            << ctag << ">(sc, " << body << "{(" << T << ")" << cname(op.operands[1]) << "}, " << bx << ", "
+            << new_box(rhs_apply->attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ");\n";
+          ApplyInfo ai;
+          ai.function = f.name;
+          ai.tag = tag;
+          ai.rank = st.rank();
+          ai.num_inputs = 1;
+          ai.march = cfp.march_ok;
+          ai.box = cfp.box;
+          ai.halo_input = cfp.halo_input;
+          info.applies.push_back(ai);
+        } else {
         o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";
         o << "  const nl::Val k_" << tag << " = " << op.callee << "__impl(sc, " << cname(op.operands[0]) << ", nullptr, nullptr, nullptr);\n";
         o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << ", &k_" << tag << "};\n";
-        o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<double, " << st.rank()
-          << ">, double, " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<double, " << st.rank() << ">{(double)"
+        o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank()
+          << ">, " << T << ", " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank() << ">{(" << T << ")"
           << cname(op.operands[1]) << "}, " << bx << ", " << bx << ", in_" << tag << ", nl::kPointwiseRadius2, " << dest << ");\n";
         ApplyInfo ai;
         ai.function = f.name;
@@ -464,6 +529,7 @@ struct Emitter {
         ai.march = true;
         ai.halo_input = -1;
         info.applies.push_back(ai);
+        }
       } else if (!op.callee.empty()) {
         const Function* c = m.find(op.callee);
         ValueInfo vi;

@@ -234,15 +234,20 @@ def test_c_caller_in_the_style_of_the_petsc_matmult_thunk(env, tmp_path):
         assert bits_equal(got, want), name
 
 
-def test_explicit_time_advance_steps(env):
-    """neptune_ir.time_advance {method = 0, rhs = @lap}: u + dt * lap(u), chained for several steps on
-    device-resident fields (nothing crosses PCIe between steps), bit-exact against the oracle"""
+@pytest.mark.parametrize("fixture,shape,fused", [("explicit-heat-2d.mlir", (12, 128), True),
+                                                 ("explicit-twostage-3d.mlir", (10, 9, 128), False)])
+def test_explicit_time_advance_steps(env, fixture, shape, fused):
+    """neptune_ir.time_advance {method = 0, rhs = @opdef}: u + dt * rhs(u), chained for several steps on
+    device-resident fields (nothing crosses PCIe between steps), bit-exact against the oracle.  A
+    single-apply rhs runs fused with the axpy (one kernel, two field passes); a two-apply rhs takes the
+    call + axpy form."""
     lowering, torch = env
-    text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-heat-2d.mlir").read_text()
+    text = (helpers.REPO / "tests/mlir_tests/time_stepping" / fixture).read_text()
     mod = lowering.compile_module(text)
+    assert [a["inputs"] for a in mod.report["applies"] if a["function"] == "step"] == [1 if fused else 2]
     m = oracle.Module.parse(text)
-    u = helpers.hash_field((12, 128), np.float64, seed=11)
-    a, b = torch.from_numpy(u).cuda(), torch.zeros((12, 128), dtype=torch.float64, device="cuda")
+    u = helpers.hash_field(shape, np.float64, seed=11)
+    a, b = torch.from_numpy(u).cuda(), torch.zeros(shape, dtype=torch.float64, device="cuda")
     ha, hb = u.copy(), np.zeros_like(u)
     for _ in range(6):
         mod.call("step", b, a)
@@ -254,6 +259,49 @@ def test_explicit_time_advance_steps(env):
     want = np.zeros_like(u)
     m.call("step", want, u)
     assert bits_equal(out, want)
+    # in place (state field == destination field): the apply may not write where it still reads
+    d = torch.from_numpy(u).cuda()
+    mod.call("step", d, d)
+    assert bits_equal(d.cpu().numpy(), want)
+
+
+def test_fused_time_step_on_every_kernel_and_tile(env, monkeypatch):
+    """the fused step through the direct kernel and each default march tile, with chunk seams, on a
+    3-D field whose rhs bounds leave a rim (rim cells: u + dt*u)"""
+    lowering, torch = env
+    text = (helpers.FIXTURE_DIR / "apply-3d-7pt.mlir").read_text()
+    text = text.replace("ub = [512, 512, 512]", "ub = [11, 14, 256]").replace("ub = [511, 511, 511]", "ub = [10, 12, 255]")
+    text = text.replace("lb = [1, 1, 1]", "lb = [2, 1, 1]")
+    head, _, _ = text.partition("  func.func @entry")
+    text = head + """  func.func @step(%out: memref<?x?x?xf64>, %in: memref<?x?x?xf64>) -> memref<?x?x?xf64> {
+    %fo = neptune_ir.wrap %out : memref<?x?x?xf64> -> !field
+    %fi = neptune_ir.wrap %in : memref<?x?x?xf64> -> !field
+    %u0 = neptune_ir.load %fi : !field -> !temp
+    %dt = arith.constant 2.5e-1 : f64
+    %u1 = neptune_ir.time_advance %u0, %dt {method = 0 : i32, rhs = @lap3d} : !temp, f64 -> !temp
+    neptune_ir.store %u1 to %fo : !temp to !field
+    %res = neptune_ir.unwrap %fo : !field -> memref<?x?x?xf64>
+    func.return %res : memref<?x?x?xf64>
+  }
+}
+"""
+    shape = (11, 14, 256)
+    u = helpers.hash_field(shape, np.float64, seed=21)
+    want = np.zeros_like(u)
+    oracle.Module.parse(text).call("step", want, u)
+    assert want[0, 3, 7] == u[0, 3, 7] + 0.25 * u[0, 3, 7]
+    mod = lowering.compile_module(text)
+    assert "step_ta0" in [a["tag"] for a in mod.report["applies"]]
+    d_in = torch.from_numpy(u).cuda()
+    for s in [{}, {"NEPTUNE_HIP_KERNEL": "direct"}] + [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "3"} for v in range(3)]:
+        for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in s.items():
+            monkeypatch.setenv(k, v)
+        d_out = torch.zeros(shape, dtype=torch.float64, device="cuda")
+        mod.call("step", d_out, d_in)
+        got = d_out.cpu().numpy()
+        assert bits_equal(got, want), f"{s}: " + mismatch_report(got, want)
 
 
 def test_radius_two_star_stencil_on_the_march_kernel(env):

@@ -199,7 +199,15 @@ def test_explicit_time_advance_lowers_and_implicit_stays_on_the_host():
     text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-heat-2d.mlir").read_text()
     src, report = lowering.to_hip(text)
     assert report["lowered"] == ["lap", "step"]
-    assert "lap__impl(sc, v_u0, nullptr, nullptr, nullptr)" in src and "EulerAxpy<double, 2>{(double)v_dt}" in src
+    # the rhs opdef is one apply of the state: rhs and axpy run as ONE kernel over the state
+    assert "lap__impl(sc, v_u0" not in src
+    assert "nl::run_apply<neptune_hip::ops::EulerFused<Body_lap_0, double, 2>, double, 2, 1, FP_lap_0>" in src
+    assert "kTopRadius_step_ta0[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {{1, 1, -1}" in src
+    assert [a["inputs"] for a in report["applies"] if a["function"] == "step"] == [1]
+    # a rhs opdef made of two applies is not fusable: call @rhs, then the axpy apply
+    src2, rep2s = lowering.to_hip((helpers.REPO / "tests/mlir_tests/time_stepping/explicit-twostage-3d.mlir").read_text())
+    assert "rhs__impl(sc, v_u0, nullptr, nullptr, nullptr)" in src2 and "EulerAxpy<double, 3>{(double)v_dt}" in src2
+    assert [a["inputs"] for a in rep2s["applies"] if a["function"] == "step"] == [2]
     # oracle: out = s + dt*k, two roundings, whole box (copy-through cells see k = s)
     import numpy as np
     from helpers import oracle

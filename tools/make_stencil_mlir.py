@@ -9,7 +9,8 @@ attribute/type aliases, a linear_opdef holding one apply over the interior with 
 signature (index x rank, temp x inputs), body ops in a fixed textual order, and an @entry that
 does wrap, wrap, load, apply_linear, store, unwrap, return.
 
-usage: make_stencil_mlir.py {2d5|3d7|3d27} N0 [N1 [N2]] > out.mlir
+usage: make_stencil_mlir.py {2d5|3d7|3d27} N0 [N1 [N2]] [--time-step DT] > out.mlir
+(--time-step adds @step: neptune_ir.time_advance {method = 0, rhs = @operator}; f64 kinds only)
 """
 import sys
 
@@ -75,7 +76,7 @@ def _body(kind):
     raise KeyError(kind)
 
 
-def stencil_module(kind, shape, origin=None, bounds=None):
+def stencil_module(kind, shape, origin=None, bounds=None, time_step=None):
     """NeptuneIR module text for fixture `kind` on a field of the given shape.
 
     origin : logical lower corner of the field box (default all zeros)
@@ -139,6 +140,19 @@ def stencil_module(kind, shape, origin=None, bounds=None):
     out.append(f"    %res  = neptune_ir.unwrap %fout : !field -> memref<{mr}>")
     out.append(f"    func.return %res : memref<{mr}>")
     out.append("  }")
+    if time_step is not None and elem == "f64":
+        # explicit Euler step with the operator as rhs: u1 = u0 + dt * A(u0)
+        out.append("")
+        out.append(f"  func.func @step(%out: memref<{mr}>, %in: memref<{mr}>) -> memref<{mr}> {{")
+        out.append(f"    %fout = neptune_ir.wrap %out : memref<{mr}> -> !field")
+        out.append(f"    %fin  = neptune_ir.wrap %in  : memref<{mr}> -> !field")
+        out.append("    %u0   = neptune_ir.load %fin : !field -> !temp")
+        out.append(f"    %dt   = arith.constant {time_step!r} : f64")
+        out.append(f"    %u1   = neptune_ir.time_advance %u0, %dt {{method = 0 : i32, rhs = @{opname}}} : !temp, f64 -> !temp")
+        out.append("    neptune_ir.store %u1 to %fout : !temp to !field")
+        out.append(f"    %res  = neptune_ir.unwrap %fout : !field -> memref<{mr}>")
+        out.append(f"    func.return %res : memref<{mr}>")
+        out.append("  }")
     out.append("}")
     return "\n".join(out) + "\n"
 
@@ -149,10 +163,15 @@ def main(argv):
         return 2
     kind = argv[1]
     rank = KINDS[kind][0]
+    time_step = None
+    if "--time-step" in argv:
+        k = argv.index("--time-step")
+        time_step = float(argv[k + 1])
+        del argv[k:k + 2]
     dims = [int(x) for x in argv[2:]]
     if len(dims) == 1:
         dims = dims * rank
-    sys.stdout.write(stencil_module(kind, dims))
+    sys.stdout.write(stencil_module(kind, dims, time_step=time_step))
     return 0
 
 
