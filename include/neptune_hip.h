@@ -154,6 +154,21 @@ void neptune_hip_device_sync(void);
 /* 1 if p is device (hipMalloc) memory, 0 if host/unknown */
 int neptune_hip_is_device_ptr(const void *p);
 
+/* ---- slab view for lowered modules (one process per GPU) --------------------------
+ * A lowered module is compiled once, for the GLOBAL field boxes its types declare.  While a slab is
+ * set, every lowered function of this process reads its memref arguments as the caller's LOCAL
+ * buffers: dim 0 of every declared box [lb0,ub0) becomes [max(lb0,start-ghost_lo), min(ub0,stop+ghost_hi)),
+ * apply / store / reduce bounds are clipped to the owned planes [start,stop) (logical coordinates),
+ * and a reduce returns this rank's partial sum.  The caller refreshes the ghost planes of the inputs
+ * (neptune_hip.slab.exchange_halos) before the call; result ghost planes are unspecified.  An apply
+ * that would read ghost planes of a value produced inside the same call aborts (it needs an exchange
+ * the module cannot do).  The reference has no counterpart (every PETSc object lives on
+ * PETSC_COMM_SELF, NeptunePETScRuntime.cpp:136,244,257). */
+int neptune_hip_set_slab(int64_t start, int64_t stop, int64_t ghost_lo, int64_t ghost_hi);
+int neptune_hip_clear_slab(void);
+/* out = {start, stop, ghost_lo, ghost_hi}; returns 1 if a slab is set, else 0 */
+int neptune_hip_get_slab(int64_t out[4]);
+
 /* replaces the reference's neptune_rt_free (NeptunePETScRuntime.cpp:1825 -> free()):
  * frees either a malloc'ed host result or a device result of a lowered function */
 void neptune_rt_free(void *p);

@@ -284,6 +284,13 @@ struct Emitter {
     return true;
   }
 
+  // reach of an apply along dim 0 (the slab axis), over all of its accesses
+  static int halo0_of(const Footprint& fp) {
+    int h = 0;
+    for (int k = 0; k < fp.nin; ++k) h = std::max(h, fp.radius[k][0]);
+    return h;
+  }
+
   bool emit_body(const Op& apply, const std::string& tag, Footprint& fp) {
     const Block& blk = *apply.regions[0];
     const int nin = (int)apply.operands.size();
@@ -443,7 +450,8 @@ struct Emitter {
         o << "};\n";
         o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<Body_" << tag << ", " << ctype(res.elem) << ", "
           << res.bounds.rank() << ", " << nin << ", FP_" << tag << ">(sc, Body_" << tag << "{}, " << new_box(res.bounds) << ", "
-          << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ");\n";
+          << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ", "
+          << halo0_of(fp) << ");\n";
         ApplyInfo ai;
         ai.function = f.name;
         ai.tag = tag;
@@ -504,7 +512,8 @@ struct Emitter {
           const std::string body = "neptune_hip::ops::EulerFused<Body_" + ctag + ", " + T + ", " + std::to_string(st.rank()) + ">";
           o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<" << body << ", " << T << ", " << st.rank() << ", 1, FP_"
             << ctag << ">(sc, " << body << "{(" << T << ")" << cname(op.operands[1]) << "}, " << bx << ", "
-            << new_box(rhs_apply->attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ");\n";
+            << new_box(rhs_apply->attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ", "
+            << halo0_of(cfp) << ");\n";
           ApplyInfo ai;
           ai.function = f.name;
           ai.tag = tag;

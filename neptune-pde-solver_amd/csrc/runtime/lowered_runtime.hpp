@@ -18,6 +18,9 @@
 //     apply only writes straight into a destination field when that field aliases none of its
 //     inputs -- otherwise it goes through a temporary and a device copy.
 //   * errors    : "[NeptuneRT][HIP] ..." on stderr + abort(), as the reference runtime does.
+//   * slabs     : while neptune_hip_set_slab() is in force (one process per GPU) the module's global
+//     boxes are read as this rank's local boxes and every bounds attribute is clipped to the owned
+//     planes; see include/neptune_hip.h and neptune_hip/slab.py ShardedModule.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -56,6 +59,7 @@ struct Val {
   int esize = 8;
   Box box{};              // logical box; memref values use lb = 0
   int shadow = -1;        // index of the host-backed argument this value aliases, or -1
+  bool stale_ghosts = false;  // slab mode: produced inside this call, its ghost planes hold no valid data
 };
 
 struct HostArg {          // a memref argument that arrived in host memory
@@ -72,7 +76,34 @@ struct HostArg {          // a memref argument that arrived in host memory
 
 class Scope {
  public:
-  explicit Scope(const char* fn) : fn_(fn) { neptune_hip_init_default(); }
+  explicit Scope(const char* fn) : fn_(fn) {
+    neptune_hip_init_default();
+    slab_on_ = neptune_hip_get_slab(slab_) == 1;
+  }
+  // ---- slab view -------------------------------------------------------------------------
+  bool slab() const { return slab_on_; }
+  bool has_ghosts() const { return slab_on_ && (slab_[2] > 0 || slab_[3] > 0); }
+  // a declared (global) logical box -> what this rank holds of it
+  Box local_box(const Box& b) const {
+    Box r = b;
+    if (!slab_on_) return r;
+    const int64_t lo = slab_[0] - slab_[2], hi = slab_[1] + slab_[3];
+    if (r.lb[0] < lo) r.lb[0] = lo;
+    if (r.ub[0] > hi) r.ub[0] = hi;
+    if (r.ub[0] < r.lb[0]) r.ub[0] = r.lb[0];
+    return r;
+  }
+  // a bounds attribute -> the part this rank computes: its owned planes, or (with_ghosts) all the
+  // planes it holds
+  Box owned_bounds(const Box& b, bool with_ghosts = false) const {
+    Box r = b;
+    if (!slab_on_) return r;
+    const int64_t lo = slab_[0] - (with_ghosts ? slab_[2] : 0), hi = slab_[1] + (with_ghosts ? slab_[3] : 0);
+    if (r.lb[0] < lo) r.lb[0] = lo;
+    if (r.ub[0] > hi) r.ub[0] = hi;
+    if (r.ub[0] < r.lb[0]) r.ub[0] = r.lb[0];
+    return r;
+  }
   ~Scope() {
     for (void* p : owned_) NEPTUNE_HIP_CHECK(hipFree(p));
   }
@@ -120,7 +151,13 @@ class Scope {
   }
 
   // wrap / unwrap / load: same buffer, new logical box (memref.cast ?->static must be valid)
-  Val alias(const Val& src, const Box& box, const char* op) {
+  Val alias(const Val& src, const Box& declared, const char* op) {
+    Box box = local_box(declared);
+    if (slab_on_ && !strcmp(op, "neptune_ir.unwrap")) {
+      // unwrap -> memref: the zero-based box of whatever the field holds locally
+      box = src.box;
+      for (int d = 0; d < box.rank; ++d) { box.ub[d] -= box.lb[d]; box.lb[d] = 0; }
+    }
     if (box.count() != src.count || !box_matches(src, box)) {
       fprintf(stderr, "[NeptuneRT][HIP] %s: %s: buffer shape does not match the declared field/temp bounds\n", fn_, op);
       abort();
@@ -197,6 +234,8 @@ class Scope {
     return v.box.same_shape(b);
   }
   const char* fn_;
+  bool slab_on_ = false;
+  int64_t slab_[4] = {0, 0, 0, 0};
   std::vector<void*> owned_;
   std::vector<HostArg> host_args_;
 };
@@ -249,9 +288,24 @@ inline const neptune_hip_launch_cfg_t* launch_override() {
   return &cfg;
 }
 
+// `halo0`: max |offset| along dim 0 over ALL accesses of the body (slab mode: how far the apply
+// reaches into its inputs' ghost planes).
 template <class Body, class T, int RANK, int NIN, class FP>
-inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const Box& bounds, const Val* const* in,
-                     const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest) {
+inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
+                     const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest,
+                     int halo0 = 0) {
+  // slab mode: an apply that stays within its plane (halo0 == 0) and reads only values whose ghost
+  // planes are good is computed on the ghost planes too, so a stencil apply may follow it without an
+  // exchange; any other result has stale ghosts
+  bool inputs_fresh = true;
+  for (int k = 0; k < NIN; ++k) inputs_fresh = inputs_fresh && !in[k]->stale_ghosts;
+  if (sc.has_ghosts() && halo0 > 0 && !inputs_fresh)
+    die(sc.name(), "slab mode: neptune_ir.apply reads neighbouring planes of a value computed inside this call; "
+                   "its ghost planes would need a halo exchange in the middle of the function (split the function "
+                   "or run it on one GPU)");
+  const bool whole_local = sc.slab() && halo0 == 0 && inputs_fresh;
+  const Box result_box = sc.local_box(result_decl);
+  const Box bounds = sc.owned_bounds(bounds_decl, whole_local);
   neptune_hip_apply_geom_t g;
   fill_geom(g, result_box, bounds, in, NIN);
   int rc = geom_check_radius(&g, top_radius);
@@ -268,6 +322,7 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const B
   } else {
     out = sc.alloc(result_box, (int)sizeof(T));
   }
+  out.stale_ghosts = sc.has_ghosts() && !whole_local;
   const void* ptrs[NIN];
   for (int k = 0; k < NIN; ++k) ptrs[k] = in[k]->dev;
   rc = launch_apply<Body, T, RANK, NIN, FP>(body, &g, ptrs, out.dev, sc.stream(), launch_override());
@@ -277,8 +332,15 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_box, const B
 }
 
 // neptune_ir.store (DataflowLowering.cpp:165-220)
-inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds, int dtype) {
+inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds_decl, int dtype) {
   int rc;
+  Box clipped;
+  const Box* bounds = bounds_decl;
+  if (bounds_decl && sc.slab()) {  // the owned planes of the stored box
+    clipped = sc.owned_bounds(*bounds_decl);
+    bounds = &clipped;
+    if (clipped.count() == 0) return;
+  }
   if (!bounds) {
     if (src.dev == dst.dev) {  // the producing apply already wrote into the field
       sc.mark_dirty(dst);
@@ -300,8 +362,16 @@ static const int32_t kPointwiseRadius2[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_R
     {0, 0, 0}, {0, 0, 0}, {-1, -1, -1}, {-1, -1, -1}};
 
 // neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
-inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds, int dtype) {
+// slab mode: this rank's partial sum over its owned planes (the caller adds the ranks' results)
+inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, int dtype) {
   double r = 0.0;
+  Box clipped;
+  const Box* bounds = bounds_decl;
+  if (sc.slab()) {
+    clipped = sc.owned_bounds(bounds_decl ? *bounds_decl : src.box);
+    bounds = &clipped;
+    if (clipped.count() == 0) return 0.0;
+  }
   const int rc = neptune_hip_reduce_sum(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, bounds ? bounds->lb : nullptr,
                                         bounds ? bounds->ub : nullptr, &r, sc.stream());
   if (rc == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");

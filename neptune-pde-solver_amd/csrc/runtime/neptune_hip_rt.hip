@@ -179,6 +179,24 @@ int neptune_hip_is_device_ptr(const void* p) {
   return attr.type == hipMemoryTypeDevice ? 1 : 0;
 }
 
+static int64_t g_slab[4] = {0, 0, 0, 0};
+static bool g_slab_set = false;
+int neptune_hip_set_slab(int64_t start, int64_t stop, int64_t ghost_lo, int64_t ghost_hi) {
+  if (stop < start || ghost_lo < 0 || ghost_hi < 0) return NEPTUNE_HIP_EINVAL;
+  g_slab[0] = start; g_slab[1] = stop; g_slab[2] = ghost_lo; g_slab[3] = ghost_hi;
+  g_slab_set = true;
+  return NEPTUNE_HIP_OK;
+}
+int neptune_hip_clear_slab(void) {
+  g_slab_set = false;
+  return NEPTUNE_HIP_OK;
+}
+int neptune_hip_get_slab(int64_t out[4]) {
+  if (!g_slab_set) return 0;
+  for (int i = 0; i < 4; ++i) out[i] = g_slab[i];
+  return 1;
+}
+
 void neptune_rt_free(void* p) {
   if (!p) return;
   if (neptune_hip_is_device_ptr(p)) NEPTUNE_HIP_CHECK(hipFree(p));

@@ -88,6 +88,9 @@ SIGNATURES = {
     "neptune_hip_device_sync": (None, []),
     "neptune_hip_is_device_ptr": (_i, [_vp]),
     "neptune_rt_free": (None, [_vp]),
+    "neptune_hip_set_slab": (_i, [_i64, _i64, _i64, _i64]),
+    "neptune_hip_clear_slab": (_i, []),
+    "neptune_hip_get_slab": (_i, [C.POINTER(C.c_int64)]),
     "neptune_hip_check_geom": (_i, [_geom_p, _radius_p]),
     "neptune_hip_apply_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p]),
     "neptune_hip_apply_builtin_plan": (_i, [_i, _geom_p, _vpp, _vp, _cfg_p]),

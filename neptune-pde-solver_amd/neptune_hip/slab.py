@@ -235,3 +235,63 @@ class ShardedApply:
         lo, hi = self.slab.owned_planes()
         shape = self.slab.local_shape
         return [lo] + [0] * (len(shape) - 1), [hi] + list(shape[1:])
+
+
+class ShardedModule:
+    """A lowered module (neptune_hip.lowering.LoweredModule) called on a slab-decomposed field, one
+    process per GPU.  The module is compiled once for the GLOBAL boxes its types declare; under
+    neptune_hip_set_slab() its functions read their memref arguments as this rank's local buffers and
+    clip every apply / store / reduce to the owned planes (include/neptune_hip.h, lowered_runtime.hpp).
+
+        sm = ShardedModule(mod, slab)
+        sm.call("entry", out_local, in_local)          # exchanges in_local's ghost planes, then runs
+        total = sm.call("norm2", u_local)              # scalar results: partial sums, all-reduced
+
+    `slab.radius` must cover the reach of the module's applies along dim 0 (an apply that reaches
+    beyond the ghost planes it is given aborts: it would read outside its input).  A function whose
+    applies are chained through a stencil (an apply reading neighbouring planes of a value computed in
+    the same call) cannot run sharded -- it needs an exchange in the middle -- and aborts with a message
+    saying so.  No overlap of exchange and compute here: the built-in bodies' ShardedApply has that."""
+
+    def __init__(self, module, slab: Slab, group=None):
+        from . import _capi
+        self.module = module
+        self.slab = slab
+        self.group = group
+        self._lib = _capi.load()
+
+    def local_empty(self, dtype=torch.float64, device="cuda") -> torch.Tensor:
+        return torch.empty(self.slab.local_shape, dtype=dtype, device=device)
+
+    def call(self, name: str, *args, exchange: Optional[Sequence[int]] = None):
+        """`exchange`: indices of the arguments whose ghost planes are refreshed before the call
+        (default: every tensor argument but the first, the reference's @entry(out, in...) convention; pass
+        () when the caller has already exchanged)"""
+        slab = self.slab
+        if exchange is None:
+            exchange = [i for i, a in enumerate(args) if i > 0 and hasattr(a, "shape")]
+            if len(args) == 1:
+                exchange = [0]
+        if slab.world > 1:
+            for i in exchange:
+                t = getattr(args[i], "tensor", args[i])
+                for w in exchange_halos(slab, t, self.group):
+                    w.wait()
+            if any(getattr(getattr(a, "tensor", a), "is_cuda", False) for a in args):
+                torch.cuda.current_stream().synchronize()   # lowered functions launch on the null stream
+        rc = self._lib.neptune_hip_set_slab(slab.start, slab.stop, slab.r_lo, slab.r_hi)
+        if rc != 0:
+            raise ValueError("bad slab")
+        try:
+            ret = self.module.call(name, *args)
+        finally:
+            self._lib.neptune_hip_clear_slab()
+        sig = self.module.signatures[name]
+        if sig["result"] and sig["result"]["kind"] == "scalar" and slab.world > 1:
+            # a reduce returned this rank's partial sum over its owned planes
+            t = torch.tensor([ret], dtype=torch.float64)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            ret = float(t.item())
+        return ret

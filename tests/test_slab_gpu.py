@@ -29,3 +29,72 @@ def test_sharded_apply_on_one_gpu(built_libs, world, kind, shape, steps):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert f"SLAB_GPU_OK world={world}" in p.stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_lowered_module_on_one_gpu(built_libs, tmp_path, world):
+    """lowered modules (fixtures, fused and two-stage time steps, a reduce) through ShardedModule: compiled
+    once for the global boxes, called on local slab buffers under neptune_hip_set_slab()"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_CACHE_DIR=str(tmp_path))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(HERE / "slab_module_worker.py")]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert f"SLAB_MODULE_OK world={world}" in p.stdout
+
+
+CHAINED = """
+#l = #neptune_ir.location<"cell">
+#b = #neptune_ir.bounds<lb = [0], ub = [4096]>
+!t = !neptune_ir.temp<element = f64, bounds = #b, location = #l>
+!f = !neptune_ir.field<element = f64, bounds = #b, location = #l>
+module {
+  func.func @twice(%out: memref<?xf64>, %in: memref<?xf64>) -> memref<?xf64> {
+    %fo = neptune_ir.wrap %out : memref<?xf64> -> !f
+    %fi = neptune_ir.wrap %in : memref<?xf64> -> !f
+    %u = neptune_ir.load %fi : !f -> !t
+    %a = neptune_ir.apply(%u) attributes {bounds = #neptune_ir.bounds<lb = [1], ub = [4095]>} : (!t) -> !t {
+      ^bb0(%i: index, %x: !t):
+        %l = neptune_ir.access %x[-1] : !t -> f64
+        %r = neptune_ir.access %x[1] : !t -> f64
+        %s = arith.addf %l, %r : f64
+        neptune_ir.yield %s : f64
+    }
+    %b = neptune_ir.apply(%a) attributes {bounds = #neptune_ir.bounds<lb = [1], ub = [4095]>} : (!t) -> !t {
+      ^bb0(%i: index, %x: !t):
+        %l = neptune_ir.access %x[-1] : !t -> f64
+        %r = neptune_ir.access %x[1] : !t -> f64
+        %s = arith.subf %l, %r : f64
+        neptune_ir.yield %s : f64
+    }
+    neptune_ir.store %b to %fo : !t to !f
+    %res = neptune_ir.unwrap %fo : !f -> memref<?xf64>
+    func.return %res : memref<?xf64>
+  }
+}
+"""
+
+
+def test_stencil_of_stencil_refuses_to_run_sharded(built_libs, tmp_path):
+    """an apply reading neighbouring planes of a value computed in the same call needs an exchange in the
+    middle of the function: abort with a message instead of computing with stale ghost cells"""
+    script = tmp_path / "chained.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {str(HERE.parent / 'neptune-pde-solver_amd')!r})
+os.environ["NEPTUNE_CACHE_DIR"] = {str(tmp_path)!r}
+import torch
+from neptune_hip import lowering, slab
+mod = lowering.compile_module({CHAINED!r})
+whole = torch.rand(4096, dtype=torch.float64, device="cuda")
+out = torch.zeros_like(whole)
+mod.call("twice", out, whole)                       # one GPU: fine
+print("WHOLE_OK", flush=True)
+sl = slab.Slab(0, 2, 1, (0,), (4096,), 0, 2048, 0, 1)   # rank 0 of 2, one ghost cell above
+sm = slab.ShardedModule(mod, sl)
+sm.call("twice", torch.zeros(2049, dtype=torch.float64, device="cuda"), whole[:2049].clone(), exchange=())
+print("NOT_REACHED")
+""")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert "WHOLE_OK" in p.stdout and "NOT_REACHED" not in p.stdout
+    assert p.returncode != 0 and "slab mode: neptune_ir.apply reads neighbouring planes" in p.stderr
