@@ -154,6 +154,17 @@ void neptune_hip_device_sync(void);
 /* 1 if p is device (hipMalloc) memory, 0 if host/unknown */
 int neptune_hip_is_device_ptr(const void *p);
 
+/* ---- block pool for the temporaries of lowered functions ---------------------------------------------
+ * The reference mallocs every apply result (DataflowLowering.cpp:281 -> malloc).  On the device a
+ * field-sized hipMalloc/hipFree pair costs orders of magnitude more than the kernel using the block, so
+ * idle blocks are cached (at most NEPTUNE_HIP_POOL_BYTES, default a quarter of the device memory) and
+ * reused.  _release hands back a block that no stream still uses; a block that left a lowered function
+ * as its result is simply hipFree'd by neptune_rt_free, the pool does not track live blocks. */
+void *neptune_hip_pool_alloc(size_t bytes);
+void neptune_hip_pool_release(void *p, size_t bytes);
+void neptune_hip_pool_trim(void);
+size_t neptune_hip_pool_cached_bytes(void);
+
 /* ---- slab view for lowered modules (one process per GPU) --------------------------
  * A lowered module is compiled once, for the GLOBAL field boxes its types declare.  While a slab is
  * set, every lowered function of this process reads its memref arguments as the caller's LOCAL
@@ -226,6 +237,10 @@ int neptune_hip_store_box(int dtype, int rank, const void *src, const int64_t *s
 int neptune_hip_reduce_sum(int dtype, int rank, const void *src, const int64_t *src_lb,
                            const int64_t *src_ub, const int64_t *lb, const int64_t *ub,
                            double *result, void *stream);
+/* device scratch of the reductions: (2048 + 1) elements of 8 bytes, owned by the library.  Used by the
+ * fused apply+reduce kernels a lowered module carries (csrc/kernels/reduce_apply.hpp); calls that use it
+ * are serialised by the stream they run on. */
+void *neptune_hip_reduce_workspace(void);
 
 /* ------------------------------------------------------------------------------------
  * 7. helpers for tests and the bench (device-side, so 8 GiB fields never cross PCIe)

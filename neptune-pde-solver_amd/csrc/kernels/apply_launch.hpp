@@ -269,6 +269,30 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
   return NEPTUNE_HIP_KERNEL_DIRECT;
 }
 
+// geometry struct -> the direct kernel's parameter block (kernel axis order)
+template <class T, int RANK, int NIN>
+inline void fill_direct_params(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, DirectParams<T, NIN>& P) {
+  for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
+  P.out = static_cast<T*>(out);
+  int64_t shape[3];
+  for (int d = 0; d < RANK; ++d) shape[d] = g->out_ub[d] - g->out_lb[d];
+  to_axes<RANK>(shape, P.n, 1);
+  to_axes<RANK>(g->out_lb, P.olb, 0);
+  to_axes<RANK>(g->lb, P.lb, 0);
+  to_axes<RANK>(g->ub, P.ub, 1);
+  to_axes<RANK>(g->region_lb, P.rlb, 0);
+  to_axes<RANK>(g->region_ub, P.rub, 1);
+  for (int k = 0; k < NIN; ++k) {
+    int64_t m[3], sh[3];
+    for (int d = 0; d < RANK; ++d) {
+      m[d] = g->in_ub[k][d] - g->in_lb[k][d];
+      sh[d] = g->out_lb[d] - g->in_lb[k][d];
+    }
+    to_axes<RANK>(m, P.m[k], 1);
+    to_axes<RANK>(sh, P.sh[k], 0);
+  }
+}
+
 template <class Body, class T, int RANK, int NIN, class FP>
 inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                         hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
@@ -331,25 +355,7 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
   }
 
   DirectParams<T, NIN> P{};
-  for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
-  P.out = static_cast<T*>(out);
-  int64_t shape[3];
-  for (int d = 0; d < RANK; ++d) shape[d] = g->out_ub[d] - g->out_lb[d];
-  to_axes<RANK>(shape, P.n, 1);
-  to_axes<RANK>(g->out_lb, P.olb, 0);
-  to_axes<RANK>(g->lb, P.lb, 0);
-  to_axes<RANK>(g->ub, P.ub, 1);
-  to_axes<RANK>(g->region_lb, P.rlb, 0);
-  to_axes<RANK>(g->region_ub, P.rub, 1);
-  for (int k = 0; k < NIN; ++k) {
-    int64_t m[3], sh[3];
-    for (int d = 0; d < RANK; ++d) {
-      m[d] = g->in_ub[k][d] - g->in_lb[k][d];
-      sh[d] = g->out_lb[d] - g->in_lb[k][d];
-    }
-    to_axes<RANK>(m, P.m[k], 1);
-    to_axes<RANK>(sh, P.sh[k], 0);
-  }
+  fill_direct_params<T, RANK, NIN>(g, in, out, P);
   const int64_t total = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * (P.rub[2] - P.rlb[2]);
   const int64_t blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffLL) {

@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void neptune_count_mismatch(const U* __restric
 // reproducible from run to run and independent of scheduling (no atomics), but differs from the
 // serial sum by rounding: |gpu - serial| <= 2 (n-1) eps sum|x_i| (each order is within (n-1) eps
 // sum|x_i| of the exact sum).  Accumulation is in the element type, like the reference.
+constexpr int kReduceBlocks = 2048;  // partials of the first pass; the workspace holds kReduceBlocks + 1 elements
+
 struct ReduceBoxParams {
   int64_t ext[3];     // reduced box extents (I,J,K order, absent axes 1)
   int64_t off[3];     // box origin - buffer origin

@@ -46,7 +46,8 @@ std::string report_json(const LowerInfo& info) {
   for (size_t i = 0; i < info.applies.size(); ++i) {
     const ApplyInfo& a = info.applies[i];
     o << (i ? ", " : "") << "{\"function\": \"" << a.function << "\", \"tag\": \"" << a.tag << "\", \"rank\": " << a.rank
-      << ", \"inputs\": " << a.num_inputs << ", \"kernel\": \"" << (a.march ? "march" : "direct") << "\", \"shape\": \""
+      << ", \"inputs\": " << a.num_inputs << ", \"kernel\": \"" << (a.fused_reduce ? "reduce" : (a.march ? "march" : "direct"))
+      << "\", \"shape\": \""
       << (a.halo_input < 0 ? "pointwise" : (a.box ? "box" : "star")) << "\"}";
   }
   o << "]}";

@@ -356,8 +356,14 @@ struct Emitter {
     return true;
   }
 
+  struct FusedReduce {
+    std::string tag, elem, result_box, bounds_box;
+    int rank = 0, nin = 0, halo0 = 0;
+  };
+
   bool emit_function(const Function& f) {
     std::map<std::string, ValueInfo> vals;
+    std::map<std::string, FusedReduce> fused_reduce;  // apply result -> how the consuming reduce evaluates it
     const int nargs = (int)f.arg_types.size();
     for (int i = 0; i < nargs; ++i) {
       ValueInfo vi;
@@ -441,6 +447,46 @@ struct Emitter {
         vi.type = res;
         vi.uses = vals[op.results[0]].uses;
         vals[op.results[0]] = vi;
+        // single-use result consumed by a reduce a few scalar/alias ops later: the apply is evaluated
+        // inside the reduction kernel (run_apply_reduce_sum), the temp never exists
+        {
+          int consumer = -1;
+          if (vi.uses == 1)
+            for (size_t j = oi + 1; j < f.body.ops.size(); ++j) {
+              const Op& c = *f.body.ops[j];
+              if (c.name == "neptune_ir.reduce" && c.operands.at(0) == op.results[0]) { consumer = (int)j; break; }
+              const std::string& nm = c.name;
+              const bool harmless = nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" ||
+                                    ((nm.compare(0, 6, "arith.") == 0 || nm.compare(0, 5, "math.") == 0) && c.regions.empty());
+              if (!harmless) break;
+            }
+          if (consumer >= 0) {
+            FusedReduce fr;
+            fr.tag = tag;
+            fr.elem = ctype(res.elem);
+            fr.rank = res.bounds.rank();
+            fr.nin = nin;
+            fr.result_box = new_box(res.bounds);
+            fr.bounds_box = new_box(op.attrs.at("bounds").bounds);
+            fr.halo0 = halo0_of(fp);
+            o << "  // neptune_ir.apply -> " << op.results[0] << "   (evaluated inside the reduce below)\n";
+            o << "  const nl::Val* in_" << tag << "[] = {";
+            for (int k = 0; k < nin; ++k) o << (k ? ", " : "") << "&" << cname(op.operands[k]);
+            o << "};\n";
+            fused_reduce[op.results[0]] = fr;
+            ApplyInfo ai;
+            ai.function = f.name;
+            ai.tag = tag;
+            ai.rank = fp.rank;
+            ai.num_inputs = fp.nin;
+            ai.march = false;
+            ai.box = fp.box;
+            ai.halo_input = fp.halo_input;
+            ai.fused_reduce = true;
+            info.applies.push_back(ai);
+            continue;
+          }
+        }
         std::string dest = "nullptr";
         if (dest_of.count((int)oi)) dest = dest_of[(int)oi];
         else if ((int)oi == returned_producer) dest = "dest";
@@ -565,9 +611,19 @@ struct Emitter {
         }
       } else if (n == "neptune_ir.reduce") {
         const Type& in = op.types[0];
-        o << "  // neptune_ir.reduce " << op.operands[0] << " {kind = \"sum\"}   (fixed-tree device sum, blocking)\n";
         std::string bx = "nullptr";
         if (op.attrs.count("bounds")) bx = "&" + new_box(op.attrs.at("bounds").bounds);
+        auto fit = fused_reduce.find(op.operands[0]);
+        if (fit != fused_reduce.end()) {
+          const FusedReduce& fr = fit->second;
+          o << "  // neptune_ir.reduce " << op.operands[0] << " {kind = \"sum\"}   (apply + fixed-tree device sum in one kernel, blocking)\n";
+          o << "  const " << fr.elem << " " << cname(op.results[0]) << " = (" << fr.elem << ")nl::run_apply_reduce_sum<Body_" << fr.tag
+            << ", " << fr.elem << ", " << fr.rank << ", " << fr.nin << ", FP_" << fr.tag << ">(sc, Body_" << fr.tag << "{}, "
+            << fr.result_box << ", " << fr.bounds_box << ", in_" << fr.tag << ", kTopRadius_" << fr.tag << ", " << fr.halo0 << ", "
+            << bx << ");\n";
+          continue;
+        }
+        o << "  // neptune_ir.reduce " << op.operands[0] << " {kind = \"sum\"}   (fixed-tree device sum, blocking)\n";
         o << "  const " << ctype(in.elem) << " " << cname(op.results[0]) << " = (" << ctype(in.elem) << ")nl::run_reduce_sum(sc, "
           << cname(op.operands[0]) << ", " << bx << ", " << dtype_macro(in.elem) << ");\n";
       } else if ((n.compare(0, 6, "arith.") == 0 || n.compare(0, 5, "math.") == 0) && op.regions.empty()) {

@@ -12,6 +12,7 @@ struct ApplyInfo {
   std::string function, tag;
   int rank = 0, num_inputs = 0, halo_input = -1;
   bool march = false, box = false;
+  bool fused_reduce = false;  // evaluated inside the consuming reduce's kernel
 };
 struct SigType {
   std::string kind, elem;  // kind: memref | temp | field

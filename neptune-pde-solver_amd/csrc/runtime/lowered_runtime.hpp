@@ -32,6 +32,7 @@
 
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
+#include "../kernels/reduce_apply.hpp"
 
 namespace neptune_hip {
 namespace lowered {
@@ -105,7 +106,8 @@ class Scope {
     return r;
   }
   ~Scope() {
-    for (void* p : owned_) NEPTUNE_HIP_CHECK(hipFree(p));
+    // every exit path has synchronised the stream (finish / export_result), so the blocks are idle
+    for (auto& b : owned_) neptune_hip_pool_release(b.p, b.bytes);
   }
   const char* name() const { return fn_; }
   bool host_mode() const { return !host_args_.empty(); }
@@ -140,8 +142,8 @@ class Scope {
       h.host = first;
       h.bytes = (size_t)v.count * esize;
       h.dirty = false;
-      NEPTUNE_HIP_CHECK(hipMalloc(&h.dev, h.bytes));
-      owned_.push_back(h.dev);
+      h.dev = neptune_hip_pool_alloc(h.bytes);
+      owned_.push_back({h.dev, h.bytes});
       NEPTUNE_HIP_CHECK(hipMemcpy(h.dev, h.host, h.bytes, hipMemcpyHostToDevice));
       v.dev = h.dev;
       v.shadow = (int)host_args_.size();
@@ -174,8 +176,8 @@ class Scope {
     v.box = box;
     v.count = box.count();
     size_t bytes = (size_t)v.count * esize;
-    NEPTUNE_HIP_CHECK(hipMalloc(&v.dev, bytes ? bytes : 16));
-    owned_.push_back(v.dev);
+    v.dev = neptune_hip_pool_alloc(bytes);
+    owned_.push_back({v.dev, bytes});
     return v;
   }
   void mark_dirty(const Val& v) {
@@ -184,7 +186,7 @@ class Scope {
   // hand a value to the caller: its device buffer leaves this scope's ownership
   void* release(const Val& v) {
     for (size_t i = 0; i < owned_.size(); ++i)
-      if (owned_[i] == v.dev) {
+      if (owned_[i].p == v.dev) {
         owned_.erase(owned_.begin() + i);
         return v.dev;
       }
@@ -206,7 +208,7 @@ class Scope {
       void* h = malloc(bytes ? bytes : 1);
       if (!h) die(fn_, "malloc of the result failed");
       NEPTUNE_HIP_CHECK(hipMemcpy(h, v.dev, bytes, hipMemcpyDeviceToHost));
-      if (owned) NEPTUNE_HIP_CHECK(hipFree(owned));
+      if (owned) neptune_hip_pool_release(owned, bytes);
       return h;
     }
     if (owned) return owned;
@@ -214,7 +216,7 @@ class Scope {
     // the callee-allocates / caller-frees rule still holds
     void* d = nullptr;
     size_t bytes = (size_t)v.count * v.esize;
-    NEPTUNE_HIP_CHECK(hipMalloc(&d, bytes ? bytes : 16));
+    d = neptune_hip_pool_alloc(bytes);
     NEPTUNE_HIP_CHECK(hipMemcpy(d, v.dev, bytes, hipMemcpyDeviceToDevice));
     return d;
   }
@@ -236,7 +238,8 @@ class Scope {
   const char* fn_;
   bool slab_on_ = false;
   int64_t slab_[4] = {0, 0, 0, 0};
-  std::vector<void*> owned_;
+  struct Owned { void* p; size_t bytes; };
+  std::vector<Owned> owned_;
   std::vector<HostArg> host_args_;
 };
 
@@ -377,6 +380,78 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
   if (rc == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");
   if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.reduce rejected");
   return r;
+}
+
+// neptune_ir.reduce {kind = "sum"} of a single-use neptune_ir.apply result, fused: the apply's values are
+// summed as they are computed (csrc/kernels/reduce_apply.hpp); no intermediate temp, nothing written.
+template <class Body, class T, int RANK, int NIN, class FP>
+inline double run_apply_reduce_sum(Scope& sc, const Body& body, const Box& result_decl, const Box& bounds_decl,
+                                   const Val* const* in,
+                                   const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], int halo0,
+                                   const Box* reduce_decl) {
+  for (int k = 0; k < NIN; ++k)
+    if (sc.has_ghosts() && halo0 > 0 && in[k]->stale_ghosts)
+      die(sc.name(), "slab mode: neptune_ir.apply reads neighbouring planes of a value computed inside this call");
+  const Box result_box = sc.local_box(result_decl);
+  const Box bounds = sc.owned_bounds(bounds_decl);
+  const Box red = sc.owned_bounds(reduce_decl ? *reduce_decl : result_decl);
+  neptune_hip_apply_geom_t g;
+  fill_geom(g, result_box, bounds, in, NIN);
+  int rc = geom_check_radius(&g, top_radius);
+  if (rc == NEPTUNE_HIP_EOOB)
+    die(sc.name(), "neptune_ir.apply reads outside an input's bounds (undefined behaviour in the reference lowering, "
+                   "DataflowLowering.cpp:380-410); refusing to run it");
+  if (rc != NEPTUNE_HIP_OK) die(sc.name(), "malformed neptune_ir.apply geometry");
+  int64_t cells = 1;
+  for (int d = 0; d < RANK; ++d) {
+    const int64_t e = red.ub[d] - red.lb[d];
+    if (e < 0) die(sc.name(), "malformed neptune_ir.reduce bounds");
+    if (e > 0 && (red.lb[d] < result_box.lb[d] || red.ub[d] > result_box.ub[d]))
+      die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");
+    g.region_lb[d] = red.lb[d] - result_box.lb[d];
+    g.region_ub[d] = red.ub[d] - result_box.lb[d];
+    cells *= e;
+  }
+  if (cells == 0) return 0.0;  // the reference's loop never runs, the accumulator stays 0
+  const void* ptrs[NIN];
+  for (int k = 0; k < NIN; ++k) ptrs[k] = in[k]->dev;
+  DirectParams<T, NIN> P{};
+  fill_direct_params<T, RANK, NIN>(&g, ptrs, nullptr, P);
+  const int64_t eK = P.rub[2] - P.rlb[2];
+  // the kernel keeps coordinates and row indices in 32 bits
+  const int64_t lim = 0x7fffff00LL;
+  bool narrow = P.n[0] * P.n[1] < lim && P.n[2] < lim;
+  for (int k = 0; k < NIN; ++k) {
+    narrow = narrow && P.m[k][0] * P.m[k][1] < lim && P.m[k][2] < lim;
+    for (int ax = 0; ax < 3; ++ax) narrow = narrow && P.sh[k][ax] > -lim && P.sh[k][ax] < lim;
+  }
+  if (!narrow) die(sc.name(), "neptune_ir.reduce of an apply: fields with 2^31 rows or 2^31 cells per row are not supported");
+  T* part = static_cast<T*>(neptune_hip_reduce_workspace());
+  // pointwise body on 16-byte-aligned rows with all inputs in the result's box: the vector kernel
+  constexpr int VK = 16 / (int)sizeof(T);
+  bool vec = FP::MARCH_OK && FP::HALO_MASK == 0u && eK % VK == 0 && P.rlb[2] % VK == 0 && P.n[2] % VK == 0;
+  for (int k = 0; k < NIN; ++k) {
+    vec = vec && ((uintptr_t)ptrs[k] % 16 == 0);
+    for (int ax = 0; ax < 3; ++ax) vec = vec && P.sh[k][ax] == 0 && P.m[k][ax] == P.n[ax];
+  }
+  const int cells_per_chunk = 256 * (vec ? VK : 1), iter = vec ? kReduceApplyIter / 2 : kReduceApplyIter;
+  const int64_t nchunk = (eK + cells_per_chunk - 1) / cells_per_chunk;
+  const int64_t trips = ((P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * nchunk + iter - 1) / iter;
+  const int blocks = (int)(trips < kReduceBlocks ? trips : kReduceBlocks);
+  if constexpr (FP::MARCH_OK && FP::HALO_MASK == 0u) {
+    if (vec)
+      hipLaunchKernelGGL((neptune_reduce_apply_vec<Body, T, RANK, NIN>), dim3(blocks), dim3(256), 0, sc.stream(), P, body, nchunk, part);
+  } else {
+    vec = false;
+  }
+  if (!vec)
+    hipLaunchKernelGGL((neptune_reduce_apply<Body, T, RANK, NIN>), dim3(blocks), dim3(256), 0, sc.stream(), P, body, nchunk, part);
+  hipLaunchKernelGGL(neptune_reduce_final<T>, dim3(1), dim3(256), 0, sc.stream(), part, blocks, part + kReduceBlocks);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  T h = 0;
+  NEPTUNE_HIP_CHECK(hipMemcpyAsync(&h, part + kReduceBlocks, sizeof(T), hipMemcpyDeviceToHost, sc.stream()));
+  NEPTUNE_HIP_CHECK(hipStreamSynchronize(sc.stream()));
+  return (double)h;
 }
 
 template <int RANK> struct MemRefOf;

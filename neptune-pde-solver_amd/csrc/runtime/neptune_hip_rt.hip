@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
@@ -31,8 +32,12 @@ struct RuntimeState {
   int cus = 0;
   unsigned long long* counter = nullptr;  // device word for count_mismatch
   void* reduce_ws = nullptr;              // kReduceBlocks partials + 1 result (8 B each)
+  // idle device blocks kept for the temporaries of lowered functions (neptune_hip_pool_*)
+  struct PoolBlock { void* p; size_t bytes; };
+  std::vector<PoolBlock> pool;
+  size_t pool_bytes = 0;
+  long long pool_cap = -1;                // bytes the pool may hold; -1 = not yet decided
 };
-constexpr int kReduceBlocks = 2048;       // 8 workgroups per CU, fixed: the summation tree never changes
 RuntimeState& rt() {
   static RuntimeState s;
   return s;
@@ -125,6 +130,9 @@ void neptune_hip_finalize(void) {
     (void)hipFree(s.reduce_ws);
     s.reduce_ws = nullptr;
   }
+  for (auto& b : s.pool) (void)hipFree(b.p);
+  s.pool.clear();
+  s.pool_bytes = 0;
   s.inited = false;
 }
 
@@ -177,6 +185,85 @@ int neptune_hip_is_device_ptr(const void* p) {
     return 0;
   }
   return attr.type == hipMemoryTypeDevice ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- block pool
+// hipMalloc/hipFree of a field-sized block costs far more than the kernels that use it (an 8 GiB temp:
+// hundreds of milliseconds for mapping and unmapping), and a lowered function needs one for every
+// apply result it cannot write straight into a destination field.  Idle blocks are therefore kept and
+// handed out again: best fit within 25 % of the request, LIFO among equals.  Blocks are only returned
+// by scopes that have synchronised their stream, so a cached block is never in use.
+static long long pool_cap_bytes(RuntimeState& s) {
+  if (s.pool_cap < 0) {
+    const char* e = getenv("NEPTUNE_HIP_POOL_BYTES");
+    if (e && *e) {
+      s.pool_cap = atoll(e);
+    } else {
+      size_t fr = 0, tot = 0;
+      s.pool_cap = (hipMemGetInfo(&fr, &tot) == hipSuccess) ? (long long)(tot / 4) : (long long)(16ll << 30);
+    }
+    if (s.pool_cap < 0) s.pool_cap = 0;
+  }
+  return s.pool_cap;
+}
+
+void* neptune_hip_pool_alloc(size_t bytes) {
+  ensure_init();
+  RuntimeState& s = rt();
+  if (bytes == 0) bytes = 16;
+  {
+    std::lock_guard<std::mutex> lk(s.mu);
+    int best = -1;
+    for (int i = (int)s.pool.size() - 1; i >= 0; --i) {
+      const size_t b = s.pool[i].bytes;
+      if (b >= bytes && b - bytes <= bytes / 4 && (best < 0 || b < s.pool[best].bytes)) best = i;
+    }
+    if (best >= 0) {
+      void* p = s.pool[best].p;
+      s.pool_bytes -= s.pool[best].bytes;
+      s.pool.erase(s.pool.begin() + best);
+      return p;
+    }
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    neptune_hip_pool_trim();  // out of memory with idle blocks held back: give them up and retry once
+    NEPTUNE_HIP_CHECK(hipMalloc(&p, bytes));
+  }
+  return p;
+}
+
+void neptune_hip_pool_release(void* p, size_t bytes) {
+  if (!p) return;
+  RuntimeState& s = rt();
+  if (bytes == 0) bytes = 16;
+  {
+    std::lock_guard<std::mutex> lk(s.mu);
+    if (s.inited && (long long)(s.pool_bytes + bytes) <= pool_cap_bytes(s)) {
+      s.pool.push_back({p, bytes});
+      s.pool_bytes += bytes;
+      return;
+    }
+  }
+  NEPTUNE_HIP_CHECK(hipFree(p));
+}
+
+void neptune_hip_pool_trim(void) {
+  RuntimeState& s = rt();
+  std::vector<RuntimeState::PoolBlock> blocks;
+  {
+    std::lock_guard<std::mutex> lk(s.mu);
+    blocks.swap(s.pool);
+    s.pool_bytes = 0;
+  }
+  for (auto& b : blocks) NEPTUNE_HIP_CHECK(hipFree(b.p));
+}
+
+size_t neptune_hip_pool_cached_bytes(void) {
+  RuntimeState& s = rt();
+  std::lock_guard<std::mutex> lk(s.mu);
+  return s.pool_bytes;
 }
 
 static int64_t g_slab[4] = {0, 0, 0, 0};
@@ -312,6 +399,11 @@ int neptune_hip_store_box(int dtype, int rank, const void* src, const int64_t* s
 }
 
 // ---------------------------------------------------------------- reduce
+void* neptune_hip_reduce_workspace(void) {
+  ensure_init();
+  return rt().reduce_ws;
+}
+
 int neptune_hip_reduce_sum(int dtype, int rank, const void* src, const int64_t* src_lb, const int64_t* src_ub,
                            const int64_t* lb, const int64_t* ub, double* result, void* stream) {
   if (!src || !src_lb || !src_ub || !result) return NEPTUNE_HIP_EINVAL;

@@ -88,6 +88,11 @@ SIGNATURES = {
     "neptune_hip_device_sync": (None, []),
     "neptune_hip_is_device_ptr": (_i, [_vp]),
     "neptune_rt_free": (None, [_vp]),
+    "neptune_hip_reduce_workspace": (_vp, []),
+    "neptune_hip_pool_alloc": (_vp, [_sz]),
+    "neptune_hip_pool_release": (None, [_vp, _sz]),
+    "neptune_hip_pool_trim": (None, []),
+    "neptune_hip_pool_cached_bytes": (_sz, []),
     "neptune_hip_set_slab": (_i, [_i64, _i64, _i64, _i64]),
     "neptune_hip_clear_slab": (_i, []),
     "neptune_hip_get_slab": (_i, [C.POINTER(C.c_int64)]),

@@ -304,6 +304,35 @@ def test_fused_time_step_on_every_kernel_and_tile(env, monkeypatch):
         assert bits_equal(got, want), f"{s}: " + mismatch_report(got, want)
 
 
+def test_temporaries_come_from_the_block_pool(env):
+    """an apply result that cannot be written into a destination field (here: in-place update, and the rhs
+    temp of the two-stage step) is a pooled device block: cached when the call returns, reused by the next
+    call, released by neptune_hip_pool_trim"""
+    lowering, torch = env
+    from neptune_hip import _capi
+    lib = _capi.load()
+    text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-twostage-3d.mlir").read_text()
+    mod = lowering.compile_module(text)
+    u = helpers.hash_field((10, 9, 128), np.float64, seed=4)
+    want = np.zeros_like(u)
+    oracle.Module.parse(text).call("step", want, u)
+    lib.neptune_hip_pool_trim()
+    assert lib.neptune_hip_pool_cached_bytes() == 0
+    a, b = torch.from_numpy(u).cuda(), torch.zeros(u.shape, dtype=torch.float64, device="cuda")
+    mod.call("step", b, a)
+    cached = lib.neptune_hip_pool_cached_bytes()
+    assert cached >= 2 * u.nbytes            # the two temps of @rhs
+    for _ in range(3):
+        b.zero_()
+        mod.call("step", b, a)
+        assert lib.neptune_hip_pool_cached_bytes() == cached      # reused, not grown
+        assert bits_equal(b.cpu().numpy(), want)
+    lib.neptune_hip_pool_trim()
+    assert lib.neptune_hip_pool_cached_bytes() == 0
+    mod.call("step", b, a)                   # and allocation from scratch still works
+    assert bits_equal(b.cpu().numpy(), want)
+
+
 def test_radius_two_star_stencil_on_the_march_kernel(env):
     """4th-order 13-point Laplacian: 5 live planes, 2-deep J and K halos (LDS exchange of two rows,
     two-cell wave shifts, two scalar halo cells per side)"""

@@ -180,7 +180,12 @@ def test_reduce_and_scalar_results_lower():
     text = NORM.format(n0=6, n1=8, m0=5, m1=7)
     src, report = lowering.to_hip(text)
     assert 'extern "C" double norm2(' in src
-    assert "nl::run_reduce_sum(sc, v_sq, &kBox" in src and "neptune_hip::ops::sqrt(v_s)" in src
+    # the single-use apply result is evaluated inside the reduction kernel ...
+    assert "nl::run_apply_reduce_sum<Body_norm2_0, double, 2, 1, FP_norm2_0>(sc, Body_norm2_0{}" in src
+    assert "neptune_hip::ops::sqrt(v_s)" in src and report["applies"][0]["kernel"] == "reduce"
+    # ... a reduce of anything else (here: the loaded field itself) reads its operand from memory
+    src2, _ = lowering.to_hip(text.replace("neptune_ir.reduce %sq in", "neptune_ir.reduce %u in"))
+    assert "nl::run_reduce_sum(sc, v_u, &kBox" in src2 and "run_apply_reduce_sum" not in src2
     assert report["signatures"][0]["result"]["kind"] == "scalar"
     with pytest.raises(lowering.LoweringError, match='MVP reduce only supports kind="sum"'):
         lowering.verify(text.replace('kind = "sum"', 'kind = "max"'))
