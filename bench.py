@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="3d7_1024", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "march"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "direct-flat", "march"])
     ap.add_argument("--variant", type=int, default=-1, help="march tile variant (-1 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="march planes per workgroup (0 = auto)")
     ap.add_argument("--no-autotune", action="store_true",
@@ -163,8 +163,9 @@ def main():
     rank_nd = len(gshape)
     gbox = ([0] * rank_nd, list(gshape))
     gbounds = ([1] * rank_nd, [n - 1 for n in gshape])
-    kernel = {"auto": _capi.KERNEL_AUTO, "direct": _capi.KERNEL_DIRECT, "march": _capi.KERNEL_MARCH}[args.kernel]
-    cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
+    kernel = {"auto": _capi.KERNEL_AUTO, "direct": _capi.KERNEL_DIRECT, "direct-flat": _capi.KERNEL_DIRECT,
+              "march": _capi.KERNEL_MARCH}[args.kernel]
+    cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk, _capi.FLAG_DIRECT_FLAT if args.kernel == "direct-flat" else 0)
 
     emu = None
     if args.emulate_rank:

@@ -80,6 +80,8 @@ typedef struct {
 #define NEPTUNE_HIP_KERNEL_AUTO 0
 #define NEPTUNE_HIP_KERNEL_DIRECT 1 /* one thread per cell, neighbours through L1/L2   */
 #define NEPTUNE_HIP_KERNEL_MARCH 2  /* wave tiles marching along dim 0, planes in VGPRs */
+/* neptune_hip_launch_cfg_t.flags */
+#define NEPTUNE_HIP_FLAG_DIRECT_FLAT 1 /* direct kernel: flat one-lane-per-cell form instead of the rows form */
 
 /* built-in stencil bodies; each one is the body of a committed fixture
  * (tests/fixtures/mlir/...) evaluated in that file's textual op order */
@@ -123,7 +125,7 @@ typedef struct {
   int32_t variant;  /* march tile variant; negative = automatic (default tile for the stencil shape);
                        see neptune_hip_march_variant_name */
   int32_t chunk;    /* march: planes per workgroup along dim 0, 0 = auto */
-  int32_t flags;    /* reserved, must be 0 */
+  int32_t flags;    /* NEPTUNE_HIP_FLAG_* bits, 0 = defaults */
 } neptune_hip_launch_cfg_t;
 
 /* ------------------------------------------------------------------------------------

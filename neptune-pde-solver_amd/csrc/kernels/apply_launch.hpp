@@ -356,6 +356,23 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
 
   DirectParams<T, NIN> P{};
   fill_direct_params<T, RANK, NIN>(g, in, out, P);
+  // rows form when all coordinates fit 31 bits (see apply_direct.hpp); cfg->flags bit 0 forces the flat form
+  {
+    const int64_t lim = 0x7fffff00LL;
+    const int64_t eK = P.rub[2] - P.rlb[2], rows = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]);
+    bool narrow = !(cfg && (cfg->flags & NEPTUNE_HIP_FLAG_DIRECT_FLAT)) && P.n[0] * P.n[1] < lim && P.n[2] < lim;
+    for (int k = 0; k < NIN; ++k) {
+      narrow = narrow && P.m[k][0] * P.m[k][1] < lim && P.m[k][2] < lim;
+      for (int ax = 0; ax < 3; ++ax) narrow = narrow && P.sh[k][ax] > -lim && P.sh[k][ax] < lim;
+    }
+    const int64_t nchunk = (eK + 255) / 256;
+    if (narrow && rows * nchunk < lim) {
+      hipLaunchKernelGGL((neptune_apply_rows<Body, T, RANK, NIN>), dim3((uint32_t)(rows * nchunk)), dim3(256), 0, stream, P,
+                         body, (uint32_t)nchunk);
+      NEPTUNE_HIP_CHECK(hipGetLastError());
+      return NEPTUNE_HIP_OK;
+    }
+  }
   const int64_t total = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * (P.rub[2] - P.rlb[2]);
   const int64_t blocks = (total + 255) / 256;
   if (blocks > 0x7fffffffLL) {

@@ -18,54 +18,6 @@ namespace neptune_hip {
 
 constexpr int kReduceApplyIter = 8;  // row chunks per lane per trip, all their loads in flight together
 
-// wave-uniform pointer -> SGPR pair, so the load takes the "scalar base + 32-bit lane offset" form
-template <class T>
-__device__ __forceinline__ const T* uniform_ptr(const T* p) {
-  const uint64_t u = reinterpret_cast<uint64_t>(p);
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u);
-  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-  return reinterpret_cast<const T*>(((uint64_t)hi << 32) | lo);
-}
-
-// Accessor of this kernel: a wave works on ONE row at a time, so the I and J coordinates (and with
-// them each input row's base address, clamps included) are wave-uniform scalar work; per lane there is
-// a 32-bit K coordinate, one add and two clamps per access.  Same contract as DirectAcc: coordinates
-// are clamped into the input's buffer, the plan check guarantees in-bounds cells never need it.
-// Host side guarantees that every extent, every origin shift and every buffer's row count fit 31 bits.
-template <class T, int RANK, int NIN>
-struct RowAcc {
-  const DirectParams<T, NIN>& P;
-  int32_t qi, qj;  // result-physical row coordinates (uniform)
-  int32_t qk;      // result-physical K coordinate of this lane's cell
-
-  // first element of row (ci, cj) of a buffer with extents m[]: 32-bit row index, one widening multiply
-  static __device__ __forceinline__ const T* row_ptr(const T* base, int32_t ci, int32_t cj, const int64_t (&m)[3]) {
-    const uint32_t r = (uint32_t)ci * (uint32_t)m[1] + (uint32_t)cj;
-    return uniform_ptr(base + (uint64_t)r * (uint32_t)m[2]);
-  }
-  template <int IN, int... O>
-  __device__ __forceinline__ T get() const {
-    static_assert(IN >= 0 && IN < NIN, "input index out of range");
-    constexpr int oi = PickOffset<RANK, AxisMap<RANK>::I, O...>::value;
-    constexpr int oj = PickOffset<RANK, AxisMap<RANK>::J, O...>::value;
-    constexpr int ok = PickOffset<RANK, AxisMap<RANK>::K, O...>::value;
-    int32_t ci = qi + (int32_t)P.sh[IN][0] + oi;
-    int32_t cj = qj + (int32_t)P.sh[IN][1] + oj;
-    int32_t ck = qk + (int32_t)P.sh[IN][2] + ok;
-    const int32_t li = (int32_t)P.m[IN][0] - 1, lj = (int32_t)P.m[IN][1] - 1, lk = (int32_t)P.m[IN][2] - 1;
-    ci = ci < 0 ? 0 : (ci > li ? li : ci);
-    cj = cj < 0 ? 0 : (cj > lj ? lj : cj);
-    ck = ck < 0 ? 0 : (ck > lk ? lk : ck);
-    return row_ptr(P.in[IN], ci, cj, P.m[IN])[(uint32_t)ck];
-  }
-  template <int D>
-  __device__ __forceinline__ int64_t idx() const {
-    static_assert(D >= 0 && D < RANK, "index argument out of range");
-    constexpr int ax = (RANK == 3) ? D : (RANK == 2 ? (D == 0 ? 0 : 2) : 2);
-    return (int64_t)(ax == 0 ? qi : (ax == 1 ? qj : qk)) + P.olb[ax];
-  }
-};
-
 // A *row chunk* is 256 consecutive cells of one row of the reduced box (one cell per lane, coalesced).
 // Workgroups own contiguous runs of row chunks; the (row, chunk) -> (i, j, k) bookkeeping is
 // workgroup-uniform, i.e. scalar work.  P.rlb / P.rub hold the REDUCED box in result-physical

@@ -273,7 +273,7 @@ inline void fill_geom(neptune_hip_apply_geom_t& g, const Box& out, const Box& bo
 // ones that certainly execute for every in-bounds point and must therefore stay inside their
 // input's box (out of bounds = undefined behaviour in the reference, rejected here).
 // Tuning/testing override for every apply of a lowered module, read at each launch:
-//   NEPTUNE_HIP_KERNEL=direct|march   NEPTUNE_HIP_VARIANT=<tile index>   NEPTUNE_HIP_CHUNK=<planes>
+//   NEPTUNE_HIP_KERNEL=direct|direct-flat|march   NEPTUNE_HIP_VARIANT=<tile index>   NEPTUNE_HIP_CHUNK=<planes>
 // A forced march kernel that cannot take the launch (narrow or unaligned rows) is an error, as in
 // neptune_hip_apply_builtin.  Unset: the automatic choice.
 inline const neptune_hip_launch_cfg_t* launch_override() {
@@ -282,12 +282,13 @@ inline const neptune_hip_launch_cfg_t* launch_override() {
   const char* v = getenv("NEPTUNE_HIP_VARIANT");
   const char* c = getenv("NEPTUNE_HIP_CHUNK");
   if (!k && !v && !c) return nullptr;
+  const bool flat = k && !strcmp(k, "direct-flat");
   cfg.kernel = !k ? NEPTUNE_HIP_KERNEL_AUTO
-                  : (!strcmp(k, "direct") ? NEPTUNE_HIP_KERNEL_DIRECT
-                                          : (!strcmp(k, "march") ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_KERNEL_AUTO));
+                  : ((flat || !strcmp(k, "direct")) ? NEPTUNE_HIP_KERNEL_DIRECT
+                                                    : (!strcmp(k, "march") ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_KERNEL_AUTO));
   cfg.variant = v ? atoi(v) : -1;
   cfg.chunk = c ? atoi(c) : 0;
-  cfg.flags = 0;
+  cfg.flags = flat ? NEPTUNE_HIP_FLAG_DIRECT_FLAT : 0;
   return &cfg;
 }
 

@@ -22,6 +22,7 @@ MAX_INPUTS = 4
 OK, EINVAL, EUNSUPPORTED, EOOB = 0, -1, -2, -3
 F64, F32 = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MARCH = 0, 1, 2
+FLAG_DIRECT_FLAT = 1   # direct kernel: flat one-lane-per-cell form instead of the rows form
 BODY_LAP2D5_F64, BODY_LAP3D7_F64, BODY_LAP3D27_F32, BODY_LAP1D3_F64 = 0, 1, 2, 3
 
 ERROR_NAMES = {EINVAL: "NEPTUNE_HIP_EINVAL", EUNSUPPORTED: "NEPTUNE_HIP_EUNSUPPORTED", EOOB: "NEPTUNE_HIP_EOOB"}

@@ -31,9 +31,9 @@ def _in_array(inputs: Sequence[DeviceField]):
     return arr
 
 
-def make_cfg(kernel: int = _capi.KERNEL_AUTO, variant: int = -1, chunk: int = 0) -> _capi.LaunchCfg:
-    """variant -1 = the library's default tile for the stencil shape"""
-    return _capi.LaunchCfg(kernel, variant, chunk, 0)
+def make_cfg(kernel: int = _capi.KERNEL_AUTO, variant: int = -1, chunk: int = 0, flags: int = 0) -> _capi.LaunchCfg:
+    """variant -1 = the library's default tile for the stencil shape; flags: _capi.FLAG_DIRECT_FLAT"""
+    return _capi.LaunchCfg(kernel, variant, chunk, flags)
 
 
 def geom_for(inputs: Sequence[DeviceField], out: DeviceField, bounds: Box, region: Optional[Box] = None):

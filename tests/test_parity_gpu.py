@@ -60,13 +60,22 @@ SHAPES = {
 }
 
 
+def _kernel_cfg(nh, kernel):
+    """"direct" = rows form (a workgroup per row chunk, scalar row addressing), "direct-flat" = one lane per
+    cell with 64-bit index math (the form that takes fields beyond 2^31 rows), "march" """
+    if kernel == "march":
+        return nh.apply.make_cfg(nh.capi.KERNEL_MARCH)
+    return nh.apply.make_cfg(nh.capi.KERNEL_DIRECT, flags=nh.capi.FLAG_DIRECT_FLAT if kernel == "direct-flat" else 0)
+
+
+@pytest.mark.parametrize("form", ["direct", "direct-flat"])
 @pytest.mark.parametrize("kind", ["2d5", "3d7", "3d27"])
-def test_direct_kernel_bit_exact(nh, kind):
+def test_direct_kernel_bit_exact(nh, kind, form):
     for shape in SHAPES[kind]:
         u = helpers.hash_field(shape, KIND_DTYPE[kind], seed=5)
         want = helpers.oracle_entry(kind, u)
-        got = _run(nh, kind, u, nh.apply.make_cfg(nh.capi.KERNEL_DIRECT))
-        assert bits_equal(got, want), f"{kind} {shape} direct\n" + mismatch_report(got, want)
+        got = _run(nh, kind, u, _kernel_cfg(nh, form))
+        assert bits_equal(got, want), f"{kind} {shape} {form}\n" + mismatch_report(got, want)
 
 
 @pytest.mark.parametrize("kind", ["2d5", "3d7", "3d27"])
@@ -97,32 +106,30 @@ def test_auto_plan_runs_march_on_wide_rows_and_direct_on_narrow(nh):
     assert nh.apply.plan_builtin(nh.capi.BODY_LAP3D7_F64, [fin2], fout2, ([1, 1, 1], [11, 9, 29])) == nh.capi.KERNEL_DIRECT
 
 
-@pytest.mark.parametrize("kernel", ["direct", "march"])
+@pytest.mark.parametrize("kernel", ["direct", "direct-flat", "march"])
 def test_sub_box_bounds_and_shifted_logical_origin(nh, kernel):
     """copy-through outside apply.bounds, logical origin != 0 (DataflowLowering.cpp:367-369,401-404,437-440)"""
-    k = nh.capi.KERNEL_DIRECT if kernel == "direct" else nh.capi.KERNEL_MARCH
     u = helpers.hash_field((14, 12, 136), np.float64, seed=9)
     origin = [5, -3, 7]
     bounds = ([7, -1, 10], [16, 6, 139])  # strictly inside; leaves thick copy-through margins
     want = helpers.oracle_entry("3d7", u, origin, bounds)
-    got = _run(nh, "3d7", u, nh.apply.make_cfg(k), origin, bounds)
+    got = _run(nh, "3d7", u, _kernel_cfg(nh, kernel), origin, bounds)
     assert bits_equal(got, want), mismatch_report(got, want)
     # margins are input 0, bit for bit
     assert bits_equal(got[0], u[0]) and bits_equal(got[:, :2, :], u[:, :2, :])
     u2 = helpers.hash_field((21, 264), np.float64, seed=10)
     want2 = helpers.oracle_entry("2d5", u2, [100, -50], ([103, -40], [119, 200]))
-    got2 = _run(nh, "2d5", u2, nh.apply.make_cfg(k), [100, -50], ([103, -40], [119, 200]))
+    got2 = _run(nh, "2d5", u2, _kernel_cfg(nh, kernel), [100, -50], ([103, -40], [119, 200]))
     assert bits_equal(got2, want2), mismatch_report(got2, want2)
     # empty bounds: pure copy-through
-    got3 = _run(nh, "2d5", u2, nh.apply.make_cfg(k), [0, 0], ([4, 4], [4, 9]))
+    got3 = _run(nh, "2d5", u2, _kernel_cfg(nh, kernel), [0, 0], ([4, 4], [4, 9]))
     assert bits_equal(got3, u2)
 
 
-@pytest.mark.parametrize("kernel", ["direct", "march"])
+@pytest.mark.parametrize("kernel", ["direct", "direct-flat", "march"])
 def test_regions_tile_one_apply_without_touching_other_cells(nh, kernel):
     """the slab decomposition launches edge planes and interior separately: the union must equal
     one whole-field apply and cells outside a region must keep their old value"""
-    k = nh.capi.KERNEL_DIRECT if kernel == "direct" else nh.capi.KERNEL_MARCH
     shape = (18, 10, 128)
     u = helpers.hash_field(shape, np.float64, seed=12)
     want = helpers.oracle_entry("3d7", u)
@@ -131,7 +138,7 @@ def test_regions_tile_one_apply_without_touching_other_cells(nh, kernel):
     fout = nh.fields.DeviceField.empty_like(fin)
     fout.tensor.fill_(-777.0)
     bounds = ([1, 1, 1], [17, 9, 127])
-    cfg = nh.apply.make_cfg(k)
+    cfg = _kernel_cfg(nh, kernel)
     full = lambda lo, hi: ([lo, 0, 0], [hi, shape[1], shape[2]])
     nh.apply.apply_builtin(body, [fin], fout, bounds, region=full(0, 2), cfg=cfg)
     nh.torch.cuda.synchronize()
@@ -300,8 +307,8 @@ def test_randomised_geometries_bit_exact(nh):
                     ub[-1] = lb[-1]
             u = helpers.hash_field(tuple(shape), dt, seed=int(rng.integers(1, 1 << 30)))
             want = helpers.oracle_entry(kind, u, origin, (lb, ub))
-            for kern in (nh.capi.KERNEL_DIRECT, nh.capi.KERNEL_MARCH):
-                got = _run(nh, kind, u, nh.apply.make_cfg(kern), origin, (lb, ub), prefill=3.0)
+            for kern in ("direct", "direct-flat", "march"):
+                got = _run(nh, kind, u, _kernel_cfg(nh, kern), origin, (lb, ub), prefill=3.0)
                 assert bits_equal(got, want), f"{kind} shape={shape} origin={origin} bounds={(lb, ub)} kernel={kern}\n" + \
                     mismatch_report(got, want)
             cases += 1
