@@ -196,7 +196,30 @@ def main():
             cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
         bufs[1].tensor.zero_()
         del probe
-    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap)
+    # Halo transport: RCCL send/recv between device buffers.  RCCL builds its point-to-point channels on
+    # first use (seconds): do that here, outside every timed or counted step.  If that first exchange
+    # fails on some rank (a node whose peer-to-point path is unusable), ALL ranks switch -- agreed over a
+    # gloo control group -- to staging the planes through host memory: slower, still correct, and
+    # reported as config.halo_transport.
+    halo_group, transport = None, ("rccl" if world > 1 else "none")
+    if world > 1 and args.rehearse_on_one_gpu:
+        transport = "gloo-host-staged (rehearsal)"
+    elif world > 1 and emu is None:
+        ctrl = dist.new_group(backend="gloo")
+        ok = 1
+        try:
+            for w in slab_mod.exchange_halos(sl, bufs[0].tensor):
+                w.wait()
+            torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001 - anything RCCL raises here means "no P2P"
+            ok = 0
+            print(f"[bench] rank {rank}: RCCL halo exchange failed ({type(e).__name__}: {e}); proposing host staging",
+                  file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctrl)
+        if int(flag.item()) == 0:
+            halo_group, transport = ctrl, "gloo-host-staged (RCCL point-to-point failed)"
+    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=halo_group)
     sharded = op
     stream_ptr = fields.current_stream_ptr()
     if emu is not None:
@@ -208,12 +231,6 @@ def main():
             for e in rec["edges"]:
                 _op._launch(rec, e, fout, stream_ptr)
         op = emu_step
-    elif world > 1:
-        # RCCL builds its point-to-point channels on first use (seconds): do that outside every
-        # timed or counted step, whatever --warmup says
-        for w in slab_mod.exchange_halos(sl, bufs[0].tensor):
-            w.wait()
-        torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
@@ -338,6 +355,7 @@ def main():
                 "variant": vname,
                 "chunk": int(cfg.chunk),
                 "autotuned": autotuned,
+                "halo_transport": transport,
             },
             "hbm_GBps": achieved * world if world > 1 else achieved,
             "roofline": {

@@ -165,8 +165,9 @@ def exchange_halos(slab: Slab, t: torch.Tensor, group=None) -> list:
 class ShardedApply:
     """One built-in apply over a slab-decomposed field, exchange overlapped with the interior."""
 
-    def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True):
+    def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True, group=None):
         from . import apply as _apply  # GPU path only
+        self.group = group        # process group of the halo exchange (None = default; a gloo group = host-staged)
         self._apply = _apply
         self.slab = slab
         self.body = body
@@ -217,7 +218,7 @@ class ShardedApply:
         self.ready.record(self.compute)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready)
-            works = exchange_halos(slab, fin.tensor)
+            works = exchange_halos(slab, fin.tensor, self.group)
             for w in works:
                 w.wait()              # stream-ordered: the comm stream waits for RCCL, the host does not
             self.halo_done.record(self.comm)
