@@ -182,18 +182,41 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   constexpr int VK = 16 / sizeof(T);
   constexpr int WJ = TL::WJ, WK = TL::WK, RJ = TL::RJ;
   const int64_t tileK = (int64_t)WK * kWave * VK, tileJ = (int64_t)WJ * RJ;
-  P.nK = (uint32_t)((P.N2 + tileK - 1) / tileK);
+  P.Kl = P.N2 / VK * VK - VK;
+  P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl;
+  P.nK = (uint32_t)((P.Ks + tileK - 1) / tileK);
   P.nJ = (uint32_t)((P.N1 + tileJ - 1) / tileJ);
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
   int64_t chunk = chunk_req;
   if (chunk <= 0) {
-    // Measured on MI355X (profiles/r01_sweep_report.txt, profiles/r01_slab_chunks.txt): long chunks
-    // win -- every chunk re-reads 2*R0 planes and restarts the prefetch pipeline -- as long as
-    // there is about one workgroup per CU; 128 planes for 3-D tiles (one chunk per 8-GPU slab of
-    // the 1024^3 problem), 32 rows for the 2-D march form.
-    chunk = RANK == 3 ? 128 : 32;
-    const int64_t min_blocks = 256;
-    while (chunk > 8 && ((planes + chunk - 1) / chunk) * tilesJK < min_blocks) chunk /= 2;
+    // Long chunks win -- every chunk re-reads 2*R0 planes and restarts the prefetch pipeline (measured:
+    // profiles/r01_sweep_report.txt, profiles/r01_slab_chunks.txt; 128 planes = one chunk per 8-GPU slab
+    // of the 1024^3 problem) -- but the grid runs in ROUNDS of (CUs x resident workgroups per CU)
+    // workgroups, and a last round that is nearly empty costs as much as a full one (513^3 with
+    // 128-plane chunks: 330 workgroups = 2 rounds on 256 CUs for the work of 1.3).  Pick the chunk
+    // length that minimises rounds x (planes a workgroup streams, start-up included).
+    static const int slots = [] {
+      int dev = 0, cus = 256, per_cu = 1;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, neptune_apply_march<Body, T, RANK, NIN, FP, TL>,
+                                                       kWave * WJ * WK, 0) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+      (void)hipGetLastError();
+      return cus * per_cu;
+    }();
+    constexpr int R0 = (TL::JK2 && RANK == 2) ? 0 : FP::R0;
+    const int cand3[] = {128, 96, 64, 48, 32, 24, 16}, cand2[] = {32, 24, 16, 8};
+    const int* cand = RANK == 3 ? cand3 : cand2;
+    const int ncand = RANK == 3 ? 7 : 4;
+    int64_t best_cost = -1;
+    for (int c = 0; c < ncand; ++c) {
+      const int64_t len = cand[c] < planes ? cand[c] : planes;
+      const int64_t blocks = ((planes + len - 1) / len) * tilesJK;
+      const int64_t rounds = (blocks + slots - 1) / slots;
+      const int64_t cost = rounds * (len + 2 * R0 + TL::PF + 2);
+      if (best_cost < 0 || cost < best_cost) { best_cost = cost; chunk = len; }
+    }
   }
   if (chunk > planes) chunk = planes;
   const int64_t nI = (planes + chunk - 1) / chunk;
@@ -243,7 +266,10 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
 
   bool ok = FP::MARCH_OK;
   const int64_t nK = g->out_ub[RANK - 1] - g->out_lb[RANK - 1];
-  ok = ok && (nK % VK == 0) && nK >= VK;
+  // ragged rows (nK % VK != 0): the kernel stores all whole vectors but the last, the rest of each row
+  // goes to a direct-kernel launch (launch_apply below)
+  const int64_t nK_march = (nK % VK == 0) ? nK : nK / VK * VK - VK;
+  ok = ok && nK_march >= VK;
   {
     // in-plane offsets are 32-bit in the march kernel: every extent and one plane's bytes
     // (everything but dim 0) must stay below 2^31
@@ -265,7 +291,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
     ok = ok && g->region_lb[d] == 0 && g->region_ub[d] == g->out_ub[d] - g->out_lb[d];
   if (want == NEPTUNE_HIP_KERNEL_MARCH) return ok ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_EUNSUPPORTED;
   // auto: the march kernel pays off once a row fills at least one wave
-  if (ok && nK >= (int64_t)kWave * VK) return NEPTUNE_HIP_KERNEL_MARCH;
+  if (ok && nK_march >= (int64_t)kWave * VK) return NEPTUNE_HIP_KERNEL_MARCH;
   return NEPTUNE_HIP_KERNEL_DIRECT;
 }
 
@@ -291,6 +317,41 @@ inline void fill_direct_params(const neptune_hip_apply_geom_t* g, const void* co
     to_axes<RANK>(m, P.m[k], 1);
     to_axes<RANK>(sh, P.sh[k], 0);
   }
+}
+
+// the direct kernel on g's region: rows form when all coordinates fit 31 bits (see apply_direct.hpp),
+// else -- or when `flat` asks for it -- the flat form
+template <class Body, class T, int RANK, int NIN>
+inline int launch_direct(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                         hipStream_t stream, bool flat) {
+  DirectParams<T, NIN> P{};
+  fill_direct_params<T, RANK, NIN>(g, in, out, P);
+  {
+    const int64_t lim = 0x7fffff00LL;
+    const int64_t eK = P.rub[2] - P.rlb[2], rows = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]);
+    bool narrow = !flat && P.n[0] * P.n[1] < lim && P.n[2] < lim;
+    for (int k = 0; k < NIN; ++k) {
+      narrow = narrow && P.m[k][0] * P.m[k][1] < lim && P.m[k][2] < lim;
+      for (int ax = 0; ax < 3; ++ax) narrow = narrow && P.sh[k][ax] > -lim && P.sh[k][ax] < lim;
+    }
+    const int64_t nchunk = (eK + 255) / 256;
+    if (narrow && rows * nchunk < lim) {
+      hipLaunchKernelGGL((neptune_apply_rows<Body, T, RANK, NIN>), dim3((uint32_t)(rows * nchunk)), dim3(256), 0, stream, P,
+                         body, (uint32_t)nchunk);
+      NEPTUNE_HIP_CHECK(hipGetLastError());
+      return NEPTUNE_HIP_OK;
+    }
+  }
+  const int64_t total = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * (P.rub[2] - P.rlb[2]);
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffffLL) {
+    fprintf(stderr, "[NeptuneRT][HIP] direct grid of %lld workgroups is not launchable\n", (long long)blocks);
+    abort();
+  }
+  hipLaunchKernelGGL((neptune_apply_direct<Body, T, RANK, NIN>), dim3((uint32_t)blocks), dim3(256), 0, stream, P,
+                     body);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
 }
 
 template <class Body, class T, int RANK, int NIN, class FP>
@@ -351,38 +412,17 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
       P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];
     }
     launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
+    if (P.N2 % (16 / (int)sizeof(T)) != 0) {
+      // ragged rows: cells [Ks, N2) of every row of the region -- fewer than 2*VK per row -- through the
+      // flat direct kernel (lanes run down the rows: strided, but a fraction of a percent of the field)
+      neptune_hip_apply_geom_t tail = *g;
+      tail.region_lb[RANK - 1] = P.Ks;
+      return launch_direct<Body, T, RANK, NIN>(body, &tail, in, out, stream, true);
+    }
     return NEPTUNE_HIP_OK;
   }
 
-  DirectParams<T, NIN> P{};
-  fill_direct_params<T, RANK, NIN>(g, in, out, P);
-  // rows form when all coordinates fit 31 bits (see apply_direct.hpp); cfg->flags bit 0 forces the flat form
-  {
-    const int64_t lim = 0x7fffff00LL;
-    const int64_t eK = P.rub[2] - P.rlb[2], rows = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]);
-    bool narrow = !(cfg && (cfg->flags & NEPTUNE_HIP_FLAG_DIRECT_FLAT)) && P.n[0] * P.n[1] < lim && P.n[2] < lim;
-    for (int k = 0; k < NIN; ++k) {
-      narrow = narrow && P.m[k][0] * P.m[k][1] < lim && P.m[k][2] < lim;
-      for (int ax = 0; ax < 3; ++ax) narrow = narrow && P.sh[k][ax] > -lim && P.sh[k][ax] < lim;
-    }
-    const int64_t nchunk = (eK + 255) / 256;
-    if (narrow && rows * nchunk < lim) {
-      hipLaunchKernelGGL((neptune_apply_rows<Body, T, RANK, NIN>), dim3((uint32_t)(rows * nchunk)), dim3(256), 0, stream, P,
-                         body, (uint32_t)nchunk);
-      NEPTUNE_HIP_CHECK(hipGetLastError());
-      return NEPTUNE_HIP_OK;
-    }
-  }
-  const int64_t total = (P.rub[0] - P.rlb[0]) * (P.rub[1] - P.rlb[1]) * (P.rub[2] - P.rlb[2]);
-  const int64_t blocks = (total + 255) / 256;
-  if (blocks > 0x7fffffffLL) {
-    fprintf(stderr, "[NeptuneRT][HIP] direct grid of %lld workgroups is not launchable\n", (long long)blocks);
-    abort();
-  }
-  hipLaunchKernelGGL((neptune_apply_direct<Body, T, RANK, NIN>), dim3((uint32_t)blocks), dim3(256), 0, stream, P,
-                     body);
-  NEPTUNE_HIP_CHECK(hipGetLastError());
-  return NEPTUNE_HIP_OK;
+  return launch_direct<Body, T, RANK, NIN>(body, g, in, out, stream, cfg && (cfg->flags & NEPTUNE_HIP_FLAG_DIRECT_FLAT));
 }
 
 }  // namespace neptune_hip

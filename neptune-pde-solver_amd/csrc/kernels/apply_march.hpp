@@ -37,6 +37,13 @@ struct MarchParams {
   const T* in[NIN];
   T* out;
   int32_t N0, N1, N2;      // extents along (I,J,K); identical for result and all inputs
+  // Rows need not be a whole number of 16-byte vectors.  Ks: cells [0,Ks) of every row are stored by
+  // this kernel (a multiple of VK); Kl: the last vector start that may be loaded (N2 rounded down to
+  // VK, minus VK).  Aligned rows: Ks = N2, Kl = N2-VK.  Ragged rows (N2 % VK != 0): Ks = Kl, i.e. the
+  // lane at Ks loads real cells [Ks,Ks+VK) only to serve as its left neighbour's K halo, and the cells
+  // [Ks,N2) of every row -- fewer than 2*VK -- are left to a direct-kernel launch by the caller.
+  // Rows then start at any multiple of sizeof(T): loads and stores are unaligned 16-byte accesses.
+  int32_t Ks, Kl;
   int32_t plb[3], pub[3];  // apply.bounds in result-physical coordinates (lb - out_lb)
   int64_t olb[3];          // result logical origin (only feeds the region's index arguments)
   int32_t rI0, rI1;        // planes this launch is responsible for (result-physical)
@@ -235,8 +242,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // into the field and their stores are predicated off, so they can keep taking part in the
   // workgroup barriers of the LDS exchange.
   const int32_t k0 = kw + lane * VK;
-  const bool lane_ok = k0 < P.N2;  // N2 % VK == 0, so a lane is entirely in or out
-  const uint32_t lane_b = (uint32_t)(lane_ok ? k0 : P.N2 - VK) * (uint32_t)sizeof(T);
+  const bool lane_ok = k0 < P.Ks;  // Ks % VK == 0, so a lane is entirely in or out
+  const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
   const int32_t kw_end = kw + kWave * VK;
 
   const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;

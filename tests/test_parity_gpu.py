@@ -54,9 +54,12 @@ def _variants(nh, rank):
 
 
 SHAPES = {
-    "2d5": [(3, 3), (5, 8), (17, 130), (40, 256), (33, 1024), (64, 1280), (9, 37)],
-    "3d7": [(3, 3, 4), (8, 8, 8), (6, 7, 130), (20, 18, 128), (33, 17, 256), (12, 70, 384), (5, 9, 11)],
-    "3d27": [(3, 3, 4), (8, 8, 8), (6, 7, 132), (20, 18, 256), (9, 33, 512), (5, 9, 11)],
+    # incl. ragged rows (last extent not a multiple of the 16-byte lane vector: 2^k+1 node-centred grids)
+    "2d5": [(3, 3), (5, 8), (17, 130), (40, 256), (33, 1024), (64, 1280), (9, 37), (33, 1025), (19, 131), (7, 5)],
+    "3d7": [(3, 3, 4), (8, 8, 8), (6, 7, 130), (20, 18, 128), (33, 17, 256), (12, 70, 384), (5, 9, 11), (9, 10, 257),
+            (6, 7, 131), (17, 9, 129)],
+    "3d27": [(3, 3, 4), (8, 8, 8), (6, 7, 132), (20, 18, 256), (9, 33, 512), (5, 9, 11), (6, 7, 133), (5, 9, 259),
+             (7, 6, 130), (4, 5, 9)],
 }
 
 
@@ -83,8 +86,8 @@ def test_march_kernel_every_variant_bit_exact(nh, kind):
     vk = 16 // np.dtype(KIND_DTYPE[kind]).itemsize
     rank = len(SHAPES[kind][0])
     for shape in SHAPES[kind]:
-        if shape[-1] % vk:
-            continue  # march declines rows that are not a multiple of the 16-byte lane vector
+        if shape[-1] < 3 * vk:
+            continue  # the march kernel needs at least one whole lane vector to store (ragged rows: two)
         u = helpers.hash_field(shape, KIND_DTYPE[kind], seed=6)
         want = helpers.oracle_entry(kind, u)
         for v in _variants(nh, rank):
@@ -294,8 +297,12 @@ def test_randomised_geometries_bit_exact(nh):
         vk = 16 // np.dtype(dt).itemsize
         for _ in range(14):
             shape = [int(rng.integers(3, 24)) for _ in range(rank - 1)]
-            last = int(rng.choice([4, 6, 8, 30, 64, 126, 128, 130, 200, 256, 300, 384])) // vk * vk
-            shape.append(max(last, vk * 2))
+            last = int(rng.choice([4, 6, 8, 30, 64, 126, 128, 130, 200, 256, 300, 384]))
+            if rng.integers(0, 2):
+                last = last // vk * vk                      # aligned rows
+            else:
+                last += int(rng.integers(1, vk))            # ragged rows: unaligned vector accesses + tail launch
+            shape.append(max(last, vk * 3))
             origin = [int(rng.integers(-5, 6)) for _ in range(rank)]
             lb, ub = [], []
             for d in range(rank):
@@ -340,7 +347,8 @@ module {{
 '''
 
 
-@pytest.mark.parametrize("n,origin,bounds", [(16, 0, (1, 15)), (130, -7, (-6, 122)), (4096, 0, (1, 4095)), (100000, 3, (500, 99000))])
+@pytest.mark.parametrize("n,origin,bounds", [(16, 0, (1, 15)), (130, -7, (-6, 122)), (4096, 0, (1, 4095)), (100000, 3, (500, 99000)),
+                                             (4097, 0, (1, 4096)), (100001, -2, (-1, 99998))])
 def test_rank1_fields_on_both_kernels(nh, n, origin, bounds):
     """the reference's own inputs are 1-D (@ac_lap, smoke_time_advance.mlir:13-29): a long 1-D field is one
     row, every wave takes 1 KiB of it (march kernel, single step), neighbours by wave shifts"""

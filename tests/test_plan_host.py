@@ -37,11 +37,16 @@ def test_fixture_geometries_plan_onto_the_march_kernel(built_libs):
     assert _plan(lib, _capi.BODY_LAP3D7_F64, interior_geom((512, 512, 512))) == _capi.KERNEL_MARCH
     assert _plan(lib, _capi.BODY_LAP2D5_F64, interior_geom((8192, 8192))) == _capi.KERNEL_MARCH
     assert _plan(lib, _capi.BODY_LAP3D27_F32, interior_geom((512, 512, 512))) == _capi.KERNEL_MARCH
-    # 1-D and narrow / odd rows go to the direct kernel
+    # rows narrower than a wave go to the direct kernel
     assert _plan(lib, _capi.BODY_LAP1D3_F64, interior_geom((16,))) == _capi.KERNEL_DIRECT
     assert _plan(lib, _capi.BODY_LAP3D7_F64, interior_geom((16, 16, 16))) == _capi.KERNEL_DIRECT
-    assert _plan(lib, _capi.BODY_LAP3D7_F64, interior_geom((64, 64, 129))) == _capi.KERNEL_DIRECT
-    assert _plan(lib, _capi.BODY_LAP2D5_F64, interior_geom((100, 1023))) == _capi.KERNEL_DIRECT
+    # odd last extent (node-centred 2^k+1 grids): ragged rows still march -- unaligned 16-byte accesses, the
+    # last few cells of every row go to a direct-kernel launch -- unless what is left is narrower than a wave
+    assert _plan(lib, _capi.BODY_LAP2D5_F64, interior_geom((100, 1023))) == _capi.KERNEL_MARCH
+    assert _plan(lib, _capi.BODY_LAP3D7_F64, interior_geom((65, 65, 1025))) == _capi.KERNEL_MARCH
+    assert _plan(lib, _capi.BODY_LAP3D7_F64, interior_geom((64, 64, 129))) == _capi.KERNEL_DIRECT   # 126 storable cells < 128
+    assert _plan(lib, _capi.BODY_LAP3D27_F32, interior_geom((9, 9, 263))) == _capi.KERNEL_MARCH     # 256 storable
+    assert _plan(lib, _capi.BODY_LAP3D27_F32, interior_geom((9, 9, 259))) == _capi.KERNEL_DIRECT    # 252 storable < 256
 
 
 def test_forced_kernels(built_libs):
@@ -49,9 +54,12 @@ def test_forced_kernels(built_libs):
     g = interior_geom((64, 64, 64))
     assert _plan(lib, _capi.BODY_LAP3D7_F64, g, _capi.LaunchCfg(_capi.KERNEL_MARCH, 0, 0, 0)) == _capi.KERNEL_MARCH
     assert _plan(lib, _capi.BODY_LAP3D7_F64, g, _capi.LaunchCfg(_capi.KERNEL_DIRECT, 0, 0, 0)) == _capi.KERNEL_DIRECT
-    # march cannot serve odd contiguous extents or misaligned buffers: refused, never silently rerouted
+    # march serves ragged rows (odd contiguous extent) as long as one whole lane vector is left to store ...
     odd = interior_geom((64, 64, 65))
-    assert _plan(lib, _capi.BODY_LAP3D7_F64, odd, _capi.LaunchCfg(_capi.KERNEL_MARCH, 0, 0, 0)) == _capi.EUNSUPPORTED
+    assert _plan(lib, _capi.BODY_LAP3D7_F64, odd, _capi.LaunchCfg(_capi.KERNEL_MARCH, 0, 0, 0)) == _capi.KERNEL_MARCH
+    # ... but not rows too short for that, nor misaligned buffers: refused, never silently rerouted
+    tiny = interior_geom((64, 64, 3))
+    assert _plan(lib, _capi.BODY_LAP3D7_F64, tiny, _capi.LaunchCfg(_capi.KERNEL_MARCH, 0, 0, 0)) == _capi.EUNSUPPORTED
     assert _plan(lib, _capi.BODY_LAP3D7_F64, g, _capi.LaunchCfg(_capi.KERNEL_MARCH, 0, 0, 0),
                  in_ptr=FAKE + 8) == _capi.EUNSUPPORTED
     # auto with a misaligned buffer falls back to the direct kernel
