@@ -1,0 +1,11 @@
+#!/usr/bin/env bash
+# Round profile set: the default bench command (plan-time tuning on) and, per workload, the library's default
+# tile (--no-autotune) with separate PMC passes.  Output under gpurun_out/prof_<tag>/ (copy summaries to profiles/).
+set -uo pipefail
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$ROOT"
+bash tools/profile_bench.sh 3d7_1024_default --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/prof_3d7_1024_default.log 2>&1 || exit 1
+for W in 3d7_1024 2d5_8192 3d27_512 3d7_512; do
+  bash tools/profile_bench.sh $W --workload $W --no-autotune --steps 50 --warmup 5 --no-cpu-baseline > gpurun_out/prof_$W.log 2>&1 || exit 1
+done
+echo PROFILE_ALL_OK

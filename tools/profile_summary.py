@@ -9,8 +9,21 @@ from collections import defaultdict
 out = sys.argv[1]
 
 
+import re
+
+
 def short(name):
-    for key in ("neptune_apply_march", "neptune_apply_direct", "neptune_fill_hash", "neptune_copy16", "neptune_store_box"):
+    """kernel name without the boilerplate; march kernels keep their tile (one template instantiation per tile
+    variant: RJ, WJ, WK, dpp, nt-store, PF, nt-load, lds-J, tile-form, late-J-halo)"""
+    m = re.search(r"neptune_apply_march<.*?Tile<([^>]*)>", name)
+    if m:
+        a = [x.strip() for x in m.group(1).split(",")]
+        f = lambda i: a[i] == "true"
+        tag = f"rj{a[0]}_wj{a[1]}_wk{a[2]}_pf{a[5]}" + ("_lds" if f(7) else "") + ("_jhl" if f(9) else "") + \
+              ("_tile" if f(8) else "") + ("" if f(3) else "_shfl") + ("" if f(4) else "_plainst")
+        return "neptune_apply_march[" + tag + "]"
+    for key in ("neptune_apply_direct", "neptune_apply_rows", "neptune_reduce_apply_vec", "neptune_reduce_apply", "neptune_fill_hash",
+                "neptune_copy16", "neptune_store_box"):
         if key in name:
             return key
     return name[:60]
@@ -20,7 +33,7 @@ print("# kernel stats (rocprofv3 --kernel-trace --stats)")
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            print(f"{short(row.get('Name', '')):28s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} "
+            print(f"{short(row.get('Name', '')):50s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} "
                   f"min_ns={row.get('MinNs')} max_ns={row.get('MaxNs')} total_ns={row.get('TotalDurationNs')} pct={row.get('Percentage')}")
 print("# per-dispatch durations of the apply kernel (kernel trace)")
 for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recursive=True):
@@ -47,4 +60,4 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
     for k, counters in acc.items():
         n = max(1, len(cnt[k]))
         for c, v in counters.items():
-            print(f"{os.path.basename(d):40s} {k:28s} {c:22s} total={v:.6g} per_dispatch={v / n:.6g} dispatches={n}")
+            print(f"{os.path.basename(d):40s} {k:50s} {c:22s} total={v:.6g} per_dispatch={v / n:.6g} dispatches={n}")
