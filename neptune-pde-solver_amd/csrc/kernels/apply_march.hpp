@@ -11,22 +11,26 @@
 //   * marching : a wave walks planes i = ib..ie of its (rows x columns) tile.  Plane i+R0+1
 //                is being fetched while plane i is computed; the 2*R0+1 live planes sit in
 //                VGPRs, so the i-neighbours cost no memory traffic at all.
-//   * J halo   : the RJ+2*R1 rows a wave needs are loaded by that wave; the 2*R1 extra rows
-//                are the neighbouring wave's own rows, i.e. L1/L2 hits when tiles that share
-//                rows run on the same XCD (see xcd_remap).
+//   * J halo   : a workgroup is WJ x WK waves; the 2*R1 rows a wave needs beyond its own RJ are its
+//                vertical neighbour's own rows and come through LDS (double-buffered, one barrier
+//                per plane step; Tile::LDSJ).  Only the workgroup's outermost rows are loaded
+//                twice -- L2 hits when tiles that share rows run on the same XCD (xcd_remap).
 //   * K halo   : the left/right neighbour cells come from the adjacent lane through a
-//                wave shift (DPP wave_shr/wave_shl, or ds_bpermute); the two cells just
+//                wave shift (DPP wave_shr/wave_shl, or ds_bpermute); the cells just
 //                outside the wave's span have wave-uniform addresses and are fetched with
 //                scalar loads (s_load through the constant cache), costing SGPRs, not VGPRs.
 //   * fusion   : copy-through and the bounds test are folded into the store: cells outside
 //                apply.bounds get input 0's value, cells inside get body(...).  Nothing is
 //                written twice and no intermediate buffer exists.
-//   * no LDS, no barriers: waves are independent, latency is hidden by ~16 waves/CU each
-//                keeping a whole plane of loads in flight.
+//   * inputs   : every input read at non-zero offsets (Footprint::HALO_MASK) has its own ring, K
+//                halos and prefetch slots; inputs read only at the centre are plain per-plane loads.
+//   * forms    : rank 3 marches along dim 0; rank 2 is one plane tiled in (rows, columns)
+//                (Tile::JK2) or marches down the rows; rank 1 is a single row.  Rows that are not a
+//                whole number of lane vectors are handled with unaligned accesses (MarchParams::Ks).
 //
 // Bandwidth accounting: algorithmic traffic is one read of every input cell + one write of
-// every result cell ((NIN+1)*N*sizeof(T)); redundant fetches are the J-halo rows (L2 hits)
-// and 2*R0 planes per chunk of `chunk` planes.
+// every result cell ((NIN+1)*N*sizeof(T)); redundant fetches are the workgroup-edge J-halo rows
+// and 2*R0 planes per chunk of `chunk` planes (measured: 1.01-1.11x, profiles/r01_variant_traffic_*).
 #pragma once
 #include "apply_common.hpp"
 

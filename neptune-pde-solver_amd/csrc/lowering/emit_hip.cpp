@@ -14,6 +14,11 @@
 //                                             also does the copy-through of input 0 (:258-448)
 //   store                                  -> elided when the producing apply can write straight
 //                                             into the destination field, else a device copy (:165-220)
+//   reduce {kind = "sum"}                  -> fixed-tree device sum (:589-698); of a single-use apply
+//                                             result: ONE kernel that evaluates the body and sums
+//   time_advance {method = 0, rhs = @A}    -> u + dt*A(u): one kernel when @A is a single apply of
+//                                             the state, else call + axpy apply
+//                                             (lib/Passes/HighLevelConvertion.cpp:77-120)
 //   func.func @entry                       -> exported symbol with expanded memref arguments and a
 //                                             memref struct result (upstream func-to-llvm ABI,
 //                                             NeptuneIRPassesPipeline.cpp:36-40)
