@@ -140,14 +140,16 @@ class _HostStaged:
             dst.copy_(src)
 
 
-def exchange_halos(slab: Slab, t: torch.Tensor, group=None) -> list:
-    """start the exchange; returns the work handles (call .wait() on each).
+def exchange_halos(slab: Slab, t: torch.Tensor, group=None, ops: Optional[List[dist.P2POp]] = None) -> list:
+    """start the exchange; returns the work handles (call .wait() on each).  `ops`: the result of an earlier
+    halo_ops(slab, t, group) for the same buffer (a time loop reuses two buffers: build the descriptors once).
 
     Production: RCCL send/recv straight between device buffers (backend "nccl").  If the process
     group is gloo and the buffer lives on a GPU (multi-rank rehearsal on a one-GPU box, where RCCL
     cannot pair two ranks on one device) the planes are staged through host memory instead: same
     geometry, same ordering, different transport."""
-    ops = halo_ops(slab, t, group)
+    if ops is None:
+        ops = halo_ops(slab, t, group)
     if not ops:
         return []
     if t.is_cuda and dist.get_backend(group) == "gloo":
@@ -191,6 +193,7 @@ class ShardedApply:
             lib = self._apply._capi.load()
             mk = lambda region: (self._apply.geom_for([fin], fout, self.bounds, region), self._apply._in_array([fin]))
             rec = {
+                "halo_ops": halo_ops(self.slab, fin.tensor, self.group) if self.slab.world > 1 else [],
                 "whole": mk(self._own_region()),
                 "interior": mk(self.interior) if self.interior is not None else None,
                 "edges": [mk(r) for r in self.edges],
@@ -218,7 +221,7 @@ class ShardedApply:
         self.ready.record(self.compute)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready)
-            works = exchange_halos(slab, fin.tensor, self.group)
+            works = exchange_halos(slab, fin.tensor, self.group, rec["halo_ops"])
             for w in works:
                 w.wait()              # stream-ordered: the comm stream waits for RCCL, the host does not
             self.halo_done.record(self.comm)
