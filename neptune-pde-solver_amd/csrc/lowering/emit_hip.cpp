@@ -575,20 +575,20 @@ struct Emitter {
           ai.halo_input = cfp.halo_input;
           info.applies.push_back(ai);
         } else {
-        o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";
-        o << "  const nl::Val k_" << tag << " = " << op.callee << "__impl(sc, " << cname(op.operands[0]) << ", nullptr, nullptr, nullptr);\n";
-        o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << ", &k_" << tag << "};\n";
-        o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank()
-          << ">, " << T << ", " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank() << ">{(" << T << ")"
-          << cname(op.operands[1]) << "}, " << bx << ", " << bx << ", in_" << tag << ", nl::kPointwiseRadius2, " << dest << ");\n";
-        ApplyInfo ai;
-        ai.function = f.name;
-        ai.tag = tag;
-        ai.rank = st.rank();
-        ai.num_inputs = 2;
-        ai.march = true;
-        ai.halo_input = -1;
-        info.applies.push_back(ai);
+          o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";
+          o << "  const nl::Val k_" << tag << " = " << op.callee << "__impl(sc, " << cname(op.operands[0]) << ", nullptr, nullptr, nullptr);\n";
+          o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << ", &k_" << tag << "};\n";
+          o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank()
+            << ">, " << T << ", " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank() << ">{(" << T << ")"
+            << cname(op.operands[1]) << "}, " << bx << ", " << bx << ", in_" << tag << ", nl::kPointwiseRadius2, " << dest << ");\n";
+          ApplyInfo ai;
+          ai.function = f.name;
+          ai.tag = tag;
+          ai.rank = st.rank();
+          ai.num_inputs = 2;
+          ai.march = true;
+          ai.halo_input = -1;
+          info.applies.push_back(ai);
         }
       } else if (!op.callee.empty()) {
         const Function* c = m.find(op.callee);
