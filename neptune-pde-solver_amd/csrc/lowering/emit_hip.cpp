@@ -486,7 +486,7 @@ struct Emitter {
             ai.num_inputs = fp.nin;
             ai.march = false;
             ai.box = fp.box;
-            ai.halo_input = fp.halo_input;
+            ai.halo_input = fp.halo_inputs > 0 ? std::max(fp.halo_input, 0) : -1;  // report: star/box also when the direct kernel runs it
             ai.fused_reduce = true;
             info.applies.push_back(ai);
             continue;
@@ -510,7 +510,7 @@ struct Emitter {
         ai.num_inputs = fp.nin;
         ai.march = fp.march_ok;
         ai.box = fp.box;
-        ai.halo_input = fp.halo_input;
+        ai.halo_input = fp.halo_inputs > 0 ? std::max(fp.halo_input, 0) : -1;  // report: star/box also when the direct kernel runs it
         info.applies.push_back(ai);
       } else if (n == "neptune_ir.time_advance") {
         // explicit Euler step: k = rhs(state); result = state + dt * k, over the whole box.  The
@@ -572,7 +572,7 @@ struct Emitter {
           ai.num_inputs = 1;
           ai.march = cfp.march_ok;
           ai.box = cfp.box;
-          ai.halo_input = cfp.halo_input;
+          ai.halo_input = cfp.halo_inputs > 0 ? std::max(cfp.halo_input, 0) : -1;
           info.applies.push_back(ai);
         } else {
           o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";

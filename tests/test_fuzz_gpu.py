@@ -1,0 +1,170 @@
+"""Seeded random applies through the whole route (NeptuneIR text -> lowering -> hipcc -> module ABI -> kernels),
+bit for bit against the oracle: random rank / element type / number of inputs, star and box footprints of radius
+1-2 spread over several inputs, bodies mixing arith/math ops, selects, scf.if on region index arguments with a
+conditional access, ragged and aligned rows, apply bounds tighter than the halo margin.  Every case runs on the
+automatic kernel choice, on both forms of the direct kernel and -- when the body can march -- on each default
+tile with chunk seams."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers
+from helpers import bits_equal, mismatch_report, oracle
+
+pytestmark = pytest.mark.gpu
+
+CONSTS = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 3.0, -0.0625, 1.75, 0.3125]
+
+
+def gen_apply(rng, name, rank, elem, shape):
+    nin = int(rng.integers(1, 4))
+    radius = int(rng.choice([1, 1, 2]))
+    box = radius == 1 and rank > 1 and rng.random() < 0.35
+    accesses = []                       # (input, offsets)
+    for k in range(nin):
+        style = rng.choice(["centre", "halo"]) if k > 0 else "halo"
+        accesses.append((k, (0,) * rank))
+        if style == "centre":
+            continue
+        n_off = int(rng.integers(2, 7))
+        for _ in range(n_off):
+            if box:
+                off = tuple(int(rng.integers(-1, 2)) for _ in range(rank))
+            else:
+                d = int(rng.integers(0, rank))
+                off = tuple(int(rng.choice([-radius, -1, 1, radius])) if a == d else 0 for a in range(rank))
+            if any(off) and (k, off) not in accesses:
+                accesses.append((k, off))
+    L = []
+    vals = []
+    for n, (k, off) in enumerate(accesses):
+        L.append(f"%a{n} = neptune_ir.access %in{k}[{', '.join(map(str, off))}] : !t -> {elem}")
+        vals.append(f"%a{n}")
+    cnt = 0
+
+    def const():
+        nonlocal cnt
+        cnt += 1
+        L.append(f"%c{cnt} = arith.constant {CONSTS[int(rng.integers(0, len(CONSTS)))]!r} : {elem}")
+        return f"%c{cnt}"
+
+    def binop(a, b):
+        nonlocal cnt
+        cnt += 1
+        op = rng.choice(["arith.addf", "arith.subf", "arith.mulf", "arith.addf", "arith.subf", "arith.maximumf", "arith.minimumf"])
+        L.append(f"%v{cnt} = {op} {a}, {b} : {elem}")
+        return f"%v{cnt}"
+
+    acc = vals[0]
+    for v in vals[1:]:
+        term = v
+        if rng.random() < 0.6:
+            c = const()
+            cnt += 1
+            term = f"%v{cnt}"
+            L.append(f"{term} = arith.mulf {c}, {v} : {elem}")
+        acc = binop(acc, term)
+    if rng.random() < 0.5:
+        cnt += 1
+        a = f"%v{cnt}"
+        L.append(f"{a} = math.absf {acc} : {elem}")
+        acc = binop(a, vals[0])
+    if rng.random() < 0.5:
+        c = const()
+        cnt += 1
+        L.append(f"%v{cnt} = arith.divf {acc}, {c} : {elem}")
+        acc = f"%v{cnt}"
+    if rng.random() < 0.5:                      # select on a float compare
+        z = const()
+        cnt += 1
+        L.append(f"%p{cnt} = arith.cmpf {rng.choice(['olt', 'oge', 'une', 'ogt'])}, {vals[0]}, {z} : {elem}")
+        L.append(f"%v{cnt} = arith.select %p{cnt}, {acc}, {vals[-1]} : {elem}")
+        acc = f"%v{cnt}"
+    margin = 2 if radius == 2 else 1
+    if rng.random() < 0.6:                      # scf.if on an index argument, with a conditional access
+        d = int(rng.integers(0, rank))
+        thr = int(shape[d] // 2)
+        cnt += 1
+        off = tuple(margin if a == d else 0 for a in range(rank))      # in range: taken only for i_d < thr
+        L.append(f"%thr{cnt} = arith.constant {thr} : index")
+        L.append(f"%q{cnt} = arith.cmpi slt, %i{d}, %thr{cnt} : index")
+        L.append(f"%v{cnt} = scf.if %q{cnt} -> ({elem}) {{")
+        L.append(f"  %ca{cnt} = neptune_ir.access %in0[{', '.join(map(str, off))}] : !t -> {elem}")
+        L.append(f"  %cb{cnt} = arith.addf {acc}, %ca{cnt} : {elem}")
+        L.append(f"  scf.yield %cb{cnt} : {elem}")
+        L.append("} else {")
+        L.append(f"  %w{cnt} = arith.index_cast %i{d} : index to i64")
+        L.append(f"  %wf{cnt} = arith.sitofp %w{cnt} : i64 to {elem}")
+        L.append(f"  %cc{cnt} = arith.subf {acc}, %wf{cnt} : {elem}")
+        L.append(f"  scf.yield %cc{cnt} : {elem}")
+        L.append("}")
+        acc = f"%v{cnt}"
+    L.append(f"neptune_ir.yield {acc} : {elem}")
+    lb = [margin + int(rng.integers(0, 2)) for _ in range(rank)]
+    ub = [n - margin - int(rng.integers(0, 2)) for n in shape]
+    tys = ", ".join(["!t"] * nin)
+    idx = ", ".join(f"%i{d}: index" for d in range(rank))
+    ins = ", ".join(f"%in{k}: !t" for k in range(nin))
+    text = [f"  neptune_ir.nonlinear_opdef @{name} : ({tys}) -> !t {{",
+            "  ^bb0(" + ", ".join(f"%u{k}: !t" for k in range(nin)) + "):",
+            "    %r = neptune_ir.apply(" + ", ".join(f"%u{k}" for k in range(nin)) + ") attributes {bounds = "
+            f"#neptune_ir.bounds<lb = [{', '.join(map(str, lb))}], ub = [{', '.join(map(str, ub))}]>}} : ({tys}) -> !t {{",
+            f"      ^bb0({idx}, {ins}):"] + ["        " + l for l in L] + ["    }", "    neptune_ir.return %r : !t", "  }"]
+    return "\n".join(text), nin
+
+
+def gen_module(seed):
+    """one module = one field shape and element type, three random opdefs"""
+    rng = np.random.default_rng(seed)
+    rank = int(rng.choice([1, 2, 3, 3]))
+    elem = str(rng.choice(["f64", "f64", "f32"]))
+    vk = 2 if elem == "f64" else 4
+    last = int(rng.choice([128, 192, 256, 320])) * (vk // 2) + (int(rng.integers(1, vk)) if rng.random() < 0.5 else 0)
+    shape = [int(rng.integers(6, 14)) for _ in range(rank - 1)] + [last]
+    ubs = ", ".join(map(str, shape))
+    head = ['#l = #neptune_ir.location<"cell">', f"#b = #neptune_ir.bounds<lb = [{', '.join(['0'] * rank)}], ub = [{ubs}]>",
+            f"!t = !neptune_ir.temp<element = {elem}, bounds = #b, location = #l>", "module {"]
+    ops = []
+    for n in range(3):
+        text, nin = gen_apply(rng, f"op{n}", rank, elem, shape)
+        head.append(text)
+        ops.append((f"op{n}", nin))
+    head.append("}")
+    return "\n".join(head) + "\n", tuple(shape), elem, ops
+
+
+@pytest.fixture(scope="module")
+def env(built_libs, tmp_path_factory):
+    import torch
+    assert torch.cuda.is_available()
+    os.environ["NEPTUNE_CACHE_DIR"] = str(tmp_path_factory.mktemp("neptune_cache_fuzz"))
+    from neptune_hip import lowering
+    return lowering, torch
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 703, 709, 722, 725, 730, 739, 757])
+def test_random_applies_match_the_oracle(env, monkeypatch, seed):
+    lowering, torch = env
+    text, shape, elem, ops = gen_module(seed)
+    dt = np.float64 if elem == "f64" else np.float32
+    m = oracle.Module.parse(text)
+    mod = lowering.compile_module(text)
+    kern = {a["function"]: a["kernel"] for a in mod.report["applies"]}
+    rank = len(shape)
+    for name, nin in ops:
+        ins = [helpers.hash_field(shape, dt, seed=seed + 7 * k) for k in range(nin)]
+        want = m.call(name, *ins)
+        d_ins = [torch.from_numpy(a).cuda() for a in ins]
+        settings = [{}, {"NEPTUNE_HIP_KERNEL": "direct"}, {"NEPTUNE_HIP_KERNEL": "direct-flat"}]
+        if kern[name] == "march":
+            nvar = {3: 3, 2: 2, 1: 1}[rank]
+            settings += [{"NEPTUNE_HIP_KERNEL": "march", "NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "3"} for v in range(nvar)]
+        for s in settings:
+            for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in s.items():
+                monkeypatch.setenv(k, v)
+            got = mod.call(name, *d_ins).cpu().numpy()
+            assert bits_equal(got, want), f"seed={seed} {name} shape={shape} {elem} kernel={kern[name]} {s}\n" + \
+                mismatch_report(got, want) + "\n" + text
