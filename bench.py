@@ -61,6 +61,10 @@ def parse_args():
                          "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
     ap.add_argument("--fixed-input", action="store_true",
                     help="diagnostic: every step reads field 0 and writes field 1 (no ping-pong)")
+    ap.add_argument("--lowered", action="store_true",
+                    help="run the workload's fixture through the NeptuneIR lowering (neptune-opt emitter + hipcc at start-up) "
+                         "and launch the lowered module's own apply instead of the library's built-in copy of the same body; "
+                         "the library's default tile is used (plan-time tuning covers the built-in bodies only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-planes", type=int, default=0, help="dim-0 extent of the CPU sample (0 = auto)")
     ap.add_argument("--hbm-traffic-bytes", type=float, default=None,
@@ -159,7 +163,20 @@ def main():
 
     body_name, gshape, esize, points = WORKLOADS[args.workload]
     body = nh_apply.BODY_BY_NAME[body_name]
-    dtype = nh_apply.BODY_DTYPE[body]
+    builtin_body = body
+    if args.lowered:
+        sys.path.insert(0, str(REPO / "tools"))
+        import make_stencil_mlir
+        from neptune_hip import lowering as nh_lowering
+        kind = {"lap3d7_f64": "3d7", "lap2d5_f64": "2d5", "lap3d27_f32": "3d27"}[body_name]
+        text = make_stencil_mlir.stencil_module(kind, list(gshape))
+        if world > 1:                      # one rank fills the module cache, the others load from it
+            if rank == 0:
+                nh_lowering.compile_module(text)
+            dist.barrier()
+        module = nh_lowering.compile_module(text)
+        body = module.geom_entry(make_stencil_mlir.KINDS[kind][2])     # the fixture's opdef (@lap3d, ...)
+    dtype = nh_apply.BODY_DTYPE[builtin_body]
     rank_nd = len(gshape)
     gbox = ([0] * rank_nd, list(gshape))
     gbounds = ([1] * rank_nd, [n - 1 for n in gshape])
@@ -187,7 +204,7 @@ def main():
     # exactly this rank's dominant launch (the interior region of its slab) and keeps the fastest.
     # Every tile computes the same bits; explicit --variant/--chunk/--kernel switch it off.
     autotuned = None
-    if not args.no_autotune and args.variant < 0 and args.chunk == 0 and args.kernel == "auto":
+    if not args.no_autotune and not args.lowered and args.variant < 0 and args.chunk == 0 and args.kernel == "auto":
         probe = slab_mod.ShardedApply(sl, body, gbounds, cfg=None)
         region = probe.interior if (world > 1 or args.emulate_rank) and probe.interior is not None else probe._own_region()
         cfg, tuned_ms = nh_apply.autotune_builtin(body, [bufs[0]], bufs[1], probe.bounds, region=region)
@@ -314,7 +331,7 @@ def main():
             alg_bytes = 2.0 * own_cells * esize
             kern_ms = ev_ms / args.steps  # per step on this rank's compute stream (interior + edges + waits)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        plan = nh_apply.plan_builtin(body, [bufs[0]], bufs[1], sharded.bounds, region=sharded._own_region(), cfg=cfg)
+        plan = nh_apply.plan_builtin(builtin_body, [bufs[0]], bufs[1], sharded.bounds, region=sharded._own_region(), cfg=cfg)
         auto_variant = 1 if (rank_nd == 3 and points == 27) else 0      # apply_launch.hpp: box stencils take tile 1
         vidx = cfg.variant if cfg.variant >= 0 else auto_variant
         if world > 1 and rank_nd == 2 and vidx == 0:
@@ -356,6 +373,7 @@ def main():
                 "chunk": int(cfg.chunk),
                 "autotuned": autotuned,
                 "halo_transport": transport,
+                "body": "lowered module (NeptuneIR text -> emitter -> hipcc)" if args.lowered else "library built-in (same statements)",
             },
             "hbm_GBps": achieved * world if world > 1 else achieved,
             "roofline": {

@@ -48,7 +48,8 @@ std::string report_json(const LowerInfo& info) {
     o << (i ? ", " : "") << "{\"function\": \"" << a.function << "\", \"tag\": \"" << a.tag << "\", \"rank\": " << a.rank
       << ", \"inputs\": " << a.num_inputs << ", \"kernel\": \"" << (a.fused_reduce ? "reduce" : (a.march ? "march" : "direct"))
       << "\", \"shape\": \""
-      << (a.halo_input < 0 ? "pointwise" : (a.box ? "box" : "star")) << "\"}";
+      << (a.halo_input < 0 ? "pointwise" : (a.box ? "box" : "star")) << "\", \"elem\": \"" << a.elem << "\", \"halo0\": " << a.halo0
+      << ", \"geom_symbol\": \"" << a.geom_symbol << "\"}";
   }
   o << "]}";
   return o.str();

@@ -96,7 +96,7 @@ struct Emitter {
   const Module& m;
   Diag& diag;
   LowerInfo& info;
-  std::ostringstream bodies, funcs;
+  std::ostringstream bodies, funcs, geom_entries;
   int box_counter = 0;
   std::ostringstream consts;
   Emitter(const Module& mm, Diag& d, LowerInfo& i) : m(mm), diag(d), info(i) {}
@@ -511,6 +511,20 @@ struct Emitter {
         ai.march = fp.march_ok;
         ai.box = fp.box;
         ai.halo_input = fp.halo_inputs > 0 ? std::max(fp.halo_input, 0) : -1;  // report: star/box also when the direct kernel runs it
+        ai.elem = res.elem;
+        ai.halo0 = halo0_of(fp);
+        ai.geom_symbol = tag + "__geom";
+        // Geometry-level entry of this apply's body: what neptune_hip_apply_builtin is for the library's own
+        // bodies (caller-supplied boxes, bounds, region, stream and launch configuration; no allocation,
+        // no synchronisation).  The slab decomposition drives user stencils through it.
+        geom_entries << "extern \"C\" int " << ai.geom_symbol
+                     << "(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,\n"
+                     << "    const neptune_hip_launch_cfg_t* cfg) {\n"
+                     << "  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;\n"
+                     << "  const int rc = neptune_hip::geom_check_radius(g, kTopRadius_" << tag << ");\n"
+                     << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
+                     << "  return neptune_hip::launch_apply<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
+                     << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n\n";
         info.applies.push_back(ai);
       } else if (n == "neptune_ir.time_advance") {
         // explicit Euler step: k = rhs(state); result = state + dt * k, over the whole box.  The
@@ -758,7 +772,9 @@ struct Emitter {
       << consts.str() << "\n"
       << bodies.str() << "}  // namespace\n\n"
       << fwd.str() << "\n"
-      << funcs.str();
+      << funcs.str()
+      << "// ---- geometry-level entries (one per apply; see include/neptune_hip.h neptune_hip_apply_builtin) ----\n"
+      << geom_entries.str();
     for (auto& s : info.skipped) o << "// not lowered: @" << s.first << ": " << s.second << "\n";
     out = o.str();
     return true;

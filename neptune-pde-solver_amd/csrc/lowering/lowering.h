@@ -13,6 +13,9 @@ struct ApplyInfo {
   int rank = 0, num_inputs = 0, halo_input = -1;
   bool march = false, box = false;
   bool fused_reduce = false;  // evaluated inside the consuming reduce's kernel
+  std::string elem;           // element type of the apply
+  int halo0 = 0;              // reach along dim 0 (what a slab decomposition must hold as ghost planes)
+  std::string geom_symbol;    // exported geometry-level entry (empty: none)
 };
 struct SigType {
   std::string kind, elem;  // kind: memref | temp | field

@@ -40,14 +40,19 @@ def geom_for(inputs: Sequence[DeviceField], out: DeviceField, bounds: Box, regio
     return make_geom(out.box, bounds, [f.box for f in inputs], region)
 
 
-def apply_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+def apply_builtin(body, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
                   region: Optional[Box] = None, cfg: Optional[_capi.LaunchCfg] = None,
                   stream: Optional[int] = None) -> None:
-    """out = apply(inputs) {bounds} with the built-in body; asynchronous on `stream`."""
+    """out = apply(inputs) {bounds}; asynchronous on `stream`.  `body`: a built-in body id, or the geometry-level
+    entry of a lowered module's apply (neptune_hip.lowering.LoweredModule.geom_entry)."""
     lib = _capi.load()
     g = geom_for(inputs, out, bounds, region)
-    rc = lib.neptune_hip_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
-                                       current_stream_ptr() if stream is None else stream,
+    st = current_stream_ptr() if stream is None else stream
+    if hasattr(body, "fn"):
+        rc = body(g, _in_array(inputs), out.ptr, st, cfg)
+        _capi.check(rc, body.symbol)
+        return
+    rc = lib.neptune_hip_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr, st,
                                        C.byref(cfg) if cfg is not None else None)
     _capi.check(rc, "neptune_hip_apply_builtin")
 

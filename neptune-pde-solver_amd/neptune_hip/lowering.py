@@ -100,6 +100,24 @@ def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: 
     return LoweredModule(so_path, json.loads(rep_path.read_text()))
 
 
+class GeomEntry:
+    """one apply of a lowered module, callable with an explicit geometry (see LoweredModule.geom_entry)"""
+
+    def __init__(self, module: "LoweredModule", info: dict):
+        self.module = module            # keeps the shared object loaded
+        self.info = info
+        self.symbol = info["geom_symbol"]
+        self.rank, self.num_inputs, self.halo0 = info["rank"], info["inputs"], info["halo0"]
+        self.dtype = _capi.F64 if info["elem"] == "f64" else _capi.F32
+        self.fn = getattr(module.lib, self.symbol)
+        self.fn.restype = C.c_int
+        self.fn.argtypes = [C.POINTER(_capi.ApplyGeom), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                            C.POINTER(_capi.LaunchCfg)]
+
+    def __call__(self, geom, in_array, out_ptr, stream, cfg=None) -> int:
+        return self.fn(C.byref(geom), in_array, out_ptr, stream, C.byref(cfg) if cfg is not None else None)
+
+
 class LoweredModule:
     """a compiled module: call exported symbols with numpy arrays (host buffers: staged through the
     device, result comes back in malloc'ed host memory) or with DeviceField / torch CUDA tensors
@@ -126,6 +144,16 @@ class LoweredModule:
     @property
     def symbols(self) -> List[str]:
         return list(self.signatures)
+
+    def geom_entry(self, function: str, index: int = 0) -> "GeomEntry":
+        """geometry-level entry of the `index`-th apply of @function: the module's counterpart of
+        neptune_hip_apply_builtin (caller-supplied boxes / bounds / region / stream / launch cfg).  Accepted
+        wherever the built-in body ids are: neptune_hip.apply.apply_builtin, plan-free region launches,
+        neptune_hip.slab.ShardedApply."""
+        cands = [a for a in self.report["applies"] if a["function"] == function and a.get("geom_symbol")]
+        if index >= len(cands):
+            raise KeyError(f"@{function} has no apply #{index} with a geometry-level entry")
+        return GeomEntry(self, cands[index])
 
     def call(self, name: str, *args):
         sig = self.signatures[name]

@@ -165,7 +165,10 @@ def exchange_halos(slab: Slab, t: torch.Tensor, group=None, ops: Optional[List[d
 
 
 class ShardedApply:
-    """One built-in apply over a slab-decomposed field, exchange overlapped with the interior."""
+    """One apply over a slab-decomposed field, exchange overlapped with the interior.  `body`: a built-in
+    body id (neptune_hip._capi.BODY_*) or the geometry-level entry of a lowered module's apply
+    (LoweredModule.geom_entry) -- any user stencil; `slab.radius` must be its reach along dim 0
+    (GeomEntry.halo0).  Several inputs: pass lists of fields; every input's ghost planes are exchanged."""
 
     def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True, group=None):
         from . import apply as _apply  # GPU path only
@@ -186,14 +189,20 @@ class ShardedApply:
     # ---- launch records: geometry structs and argument arrays are built once per (input, output)
     # pair; a step is then a handful of ctypes calls (keeps the host ahead of sub-millisecond kernels)
     def _records(self, fin, fout):
-        key = (fin.ptr, fout.ptr)
+        fins = list(fin) if isinstance(fin, (list, tuple)) else [fin]
+        key = (tuple(f.ptr for f in fins), fout.ptr)
         rec = self._cache.get(key)
         if rec is None:
             import ctypes as C
             lib = self._apply._capi.load()
-            mk = lambda region: (self._apply.geom_for([fin], fout, self.bounds, region), self._apply._in_array([fin]))
+            mk = lambda region: (self._apply.geom_for(fins, fout, self.bounds, region), self._apply._in_array(fins))
+            hops = []
+            if self.slab.world > 1:
+                for f in fins:
+                    hops += halo_ops(self.slab, f.tensor, self.group)
             rec = {
-                "halo_ops": halo_ops(self.slab, fin.tensor, self.group) if self.slab.world > 1 else [],
+                "halo_ops": hops,
+                "tensors": [f.tensor for f in fins],
                 "whole": mk(self._own_region()),
                 "interior": mk(self.interior) if self.interior is not None else None,
                 "edges": [mk(r) for r in self.edges],
@@ -206,9 +215,12 @@ class ShardedApply:
 
     def _launch(self, rec, which, fout, st) -> None:
         g, ins = which
-        rc = rec["fn"](self.body, rec["byref"](g), ins, fout.ptr, st, rec["cfg"])
+        if hasattr(self.body, "fn"):   # a lowered module's apply
+            rc = self.body.fn(rec["byref"](g), ins, fout.ptr, st, rec["cfg"])
+        else:
+            rc = rec["fn"](self.body, rec["byref"](g), ins, fout.ptr, st, rec["cfg"])
         if rc < 0:
-            raise self._apply._capi.NeptuneHipError(rc, "neptune_hip_apply_builtin")
+            raise self._apply._capi.NeptuneHipError(rc, getattr(self.body, "symbol", "neptune_hip_apply_builtin"))
 
     def __call__(self, fin, fout) -> None:
         slab = self.slab
@@ -221,7 +233,7 @@ class ShardedApply:
         self.ready.record(self.compute)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready)
-            works = exchange_halos(slab, fin.tensor, self.group, rec["halo_ops"])
+            works = exchange_halos(slab, rec["tensors"][0], self.group, rec["halo_ops"])
             for w in works:
                 w.wait()              # stream-ordered: the comm stream waits for RCCL, the host does not
             self.halo_done.record(self.comm)

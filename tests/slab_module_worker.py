@@ -72,6 +72,45 @@ def run_case(rank, world, text, symbol, shape, steps, check_oracle=True):
     return helpers.bits_equal(got, want[sl.start:sl.stop])
 
 
+def run_geom_entry_case(rank, world, text, function, shape, radius, nin, steps):
+    """the module's apply through ShardedApply (exchange overlapped with the interior launch, then the edge
+    launches) via its geometry-level entry, against the single-process call of the exported opdef"""
+    from neptune_hip import fields
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry(function)
+    assert entry.halo0 == radius and entry.num_inputs == nin
+    us = [helpers.hash_field(shape, np.float64, seed=29 + k) for k in range(nin)]
+    # single process: chain the exported opdef `steps` times on input 0, the other inputs stay fixed
+    cur = [torch.from_numpy(u).cuda() for u in us]
+    for _ in range(steps):
+        cur[0] = mod.call(function, *cur)
+    want = cur[0].cpu().numpy()
+    gbox = ([0] * len(shape), list(shape))
+    sl = slab_mod.decompose(gbox, radius, rank, world)
+    lo, hi = sl.owned_planes()
+
+    def local_field(u):
+        loc = np.full(sl.local_shape, np.nan)
+        loc[lo:hi] = u[sl.start:sl.stop]
+        return fields.DeviceField.from_numpy(loc, sl.local_lb)
+
+    ins = [local_field(u) for u in us]
+    out = fields.DeviceField(sl.local_lb, sl.local_ub, entry.dtype)
+    out.tensor.fill_(float("nan"))
+    bounds = None
+    import re
+    m = re.search(r"neptune_ir.apply\(.*?bounds = #neptune_ir.bounds<lb = \[([^\]]*)\], ub = \[([^\]]*)\]>", text, re.S)
+    bounds = ([int(x) for x in m.group(1).split(",")], [int(x) for x in m.group(2).split(",")])
+    op = slab_mod.ShardedApply(sl, entry, bounds)
+    a, b = ins[0], out
+    for _ in range(steps):
+        op([a] + ins[1:], b)
+        a, b = b, a
+    torch.cuda.synchronize()
+    got = a.numpy()[lo:hi]
+    return helpers.bits_equal(got, want[sl.start:sl.stop])
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -88,6 +127,14 @@ def main():
     ok["two_stage_step"] = run_case(rank, world, two, "step", (10, 9, 128), 2)
     text2 = make_stencil_mlir.stencil_module("2d5", [40, 512], time_step=0.0625)
     ok["entry_2d"] = run_case(rank, world, text2, "entry", (40, 512), 4)
+    # any lowered apply through the overlapped ShardedApply route (geometry-level entries)
+    ok["geom_entry_7pt"] = run_geom_entry_case(rank, world, text, "lap3d", shape, 1, 1, 3)
+    l13 = (REPO / "tests/mlir_tests/conversion_tests/apply-3d-13pt.mlir").read_text()
+    ok["geom_entry_13pt_radius2"] = run_geom_entry_case(rank, world, l13, "lap13", (20, 18, 256), 2, 1, 2)
+    import test_multihalo_gpu as mh
+    shp, elem, nin, acc, margin, _ = mh.CASES["swe3d_two_stars"]
+    swe = mh.module_text((24, 10, 128), elem, nin, acc, [1, 1, 1], [23, 9, 127])
+    ok["geom_entry_two_halo_inputs"] = run_geom_entry_case(rank, world, swe, "resid", (24, 10, 128), 1, 2, 2)
     # reduce: every rank sums its owned planes, the partial sums are added
     n0, n1 = 37, 256
     red = lowering.compile_module(SUMSQ.format(n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1))

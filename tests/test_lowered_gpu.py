@@ -304,6 +304,34 @@ def test_fused_time_step_on_every_kernel_and_tile(env, monkeypatch):
         assert bits_equal(got, want), f"{s}: " + mismatch_report(got, want)
 
 
+def test_geometry_level_entry_tiles_regions_like_the_builtin_bodies(env):
+    """LoweredModule.geom_entry: a user stencil launched region by region on caller-owned fields (what the slab
+    decomposition does), equal to the module's own whole-field call; bad geometry is refused, not run"""
+    lowering, torch = env
+    from neptune_hip import _capi, apply, fields
+    text = (helpers.FIXTURE_DIR / "apply-3d-13pt.mlir").read_text()
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("lap13")
+    shape = (20, 18, 256)
+    u = helpers.hash_field(shape, np.float64, seed=19)
+    want = mod.call("lap13", torch.from_numpy(u).cuda()).cpu().numpy()
+    assert bits_equal(want, oracle.Module.parse(text).call("lap13", u))
+    fin = fields.DeviceField.from_numpy(u)
+    fout = fields.DeviceField.empty_like(fin)
+    fout.tensor.fill_(-5.0)
+    bounds = ([2, 2, 2], [18, 16, 254])
+    full = lambda lo, hi: ([lo, 0, 0], [hi, shape[1], shape[2]])
+    for kern in (_capi.KERNEL_MARCH, _capi.KERNEL_DIRECT):
+        cfg = apply.make_cfg(kern)
+        for lo, hi in ((0, 3), (17, 20), (3, 17)):
+            apply.apply_builtin(entry, [fin], fout, bounds, region=full(lo, hi), cfg=cfg)
+        torch.cuda.synchronize()
+        assert bits_equal(fout.numpy(), want), mismatch_report(fout.numpy(), want)
+        fout.tensor.fill_(-5.0)
+    with pytest.raises(_capi.NeptuneHipError, match="EOOB"):      # bounds reaching the rim: reads outside the input
+        apply.apply_builtin(entry, [fin], fout, ([1, 2, 2], [18, 16, 254]))
+
+
 def test_temporaries_come_from_the_block_pool(env):
     """an apply result that cannot be written into a destination field (here: in-place update, and the rhs
     temp of the two-stage step) is a pooled device block: cached when the call returns, reused by the next

@@ -244,3 +244,15 @@ def test_several_halo_inputs_get_a_mask_and_shared_radii():
     shape, elem, nin, accesses, _, _ = mh.CASES["four_halo_inputs_2d"]
     src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [1, 1], [n - 1 for n in shape]))
     assert "neptune_hip::Footprint<0, 1, 0, 1, false, true, 0xfu>" in src
+
+
+def test_every_apply_gets_a_geometry_level_entry():
+    """the module's counterpart of neptune_hip_apply_builtin: explicit geometry, region, stream and launch cfg"""
+    src, report = lowering.to_hip((FIXTURE_DIR / "apply-3d-13pt.mlir").read_text())
+    a = report["applies"][0]
+    assert a["geom_symbol"] == "lap13_0__geom" and a["halo0"] == 2 and a["elem"] == "f64"
+    assert 'extern "C" int lap13_0__geom(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,' in src
+    assert "neptune_hip::launch_apply<Body_lap13_0, double, 3, 1, FP_lap13_0>(Body_lap13_0{}, g, in, out, (hipStream_t)stream, cfg)" in src
+    # applies folded into a reduce have no kernel of their own, hence no entry
+    _, rep2 = lowering.to_hip(NORM.format(n0=6, n1=8, m0=5, m1=7))
+    assert rep2["applies"][0]["geom_symbol"] == ""
