@@ -84,7 +84,7 @@ typedef struct {
 #define NEPTUNE_HIP_FLAG_DIRECT_FLAT 1 /* direct kernel: flat one-lane-per-cell form instead of the rows form */
 
 /* built-in stencil bodies; each one is the body of a committed fixture
- * (tests/fixtures/mlir/...) evaluated in that file's textual op order */
+ * (tests/mlir_tests/conversion_tests/) evaluated in that file's textual op order */
 #define NEPTUNE_HIP_BODY_LAP2D5_F64 0  /* apply-2d-5pt.mlir   */
 #define NEPTUNE_HIP_BODY_LAP3D7_F64 1  /* apply-3d-7pt.mlir   */
 #define NEPTUNE_HIP_BODY_LAP3D27_F32 2 /* apply-3d-27pt.mlir  */
