@@ -204,6 +204,25 @@ int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t *g,
                               const void *const *in, void *out, void *stream,
                               const neptune_hip_launch_cfg_t *cfg);
 
+/* A geometry-level apply entry with its body bound: what every lowered apply exports as
+ * <function>_<k>__geom (csrc/lowering/emit_hip.cpp), same arguments as neptune_hip_apply_builtin
+ * minus the body id. */
+typedef int (*neptune_hip_apply_fn)(const neptune_hip_apply_geom_t *g, const void *const *in, void *out,
+                                    void *stream, const neptune_hip_launch_cfg_t *cfg);
+
+/* `steps` applies in a row on two ping-pong fields: step s reads fields[s % 2] as input 0 and writes
+ * fields[(s + 1) % 2]; inputs 1.. (in[1..], in[0] is ignored) stay the same every step.  After the call
+ * the newest state is in fields[steps % 2].  Asynchronous on `stream`.
+ * The pair of launches is captured ONCE into a hipGraph and replayed (8 pairs = 16 launches per graph) (graphs are cached by
+ * geometry, pointers and configuration), so the per-step host cost is a fraction of a kernel launch: for
+ * fields of a few MiB -- the reference's own 1-D/2-D smoke sizes, 1024^2 -- a step is otherwise bound
+ * by launch overhead, not by the kernel.  body_or_fn: pass fn = NULL to use built-in body `body`.
+ * The reference's counterpart is the host loop around `entry` in a driver (smoke_apply.sh:70-80) and the
+ * forward-Euler loop of its runtime (NeptunePETScRuntime.cpp:677-712). */
+int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_apply_geom_t *g,
+                          void *const fields[2], const void *const *in, int64_t steps, void *stream,
+                          const neptune_hip_launch_cfg_t *cfg);
+
 /* Which kernel neptune_hip_apply_builtin would run for (body, g, cfg):
  * NEPTUNE_HIP_KERNEL_DIRECT / _MARCH, or a negative error. */
 int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t *g,

@@ -118,6 +118,31 @@ void neptune_hip_init(int device) {
   s.inited = true;
 }
 
+// state of neptune_hip_step_loop (defined further down)
+namespace {
+struct LoopKey {
+  neptune_hip_apply_fn fn;
+  int body;
+  neptune_hip_apply_geom_t g;
+  void* fields[2];
+  const void* in[NEPTUNE_HIP_MAX_INPUTS];
+  neptune_hip_launch_cfg_t cfg;
+  hipStream_t stream;
+};
+struct LoopGraph {
+  LoopKey key;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  uint64_t stamp = 0;
+};
+constexpr int kLoopGraphs = 8;
+LoopGraph g_loops[kLoopGraphs];
+uint64_t g_loop_clock = 0;
+
+hipStream_t g_loop_stream = nullptr;   // stands in for the legacy default stream, which cannot be captured
+hipEvent_t g_loop_ev[2] = {nullptr, nullptr};
+}  // namespace
+
 void neptune_hip_finalize(void) {
   RuntimeState& s = rt();
   std::lock_guard<std::mutex> lk(s.mu);
@@ -130,6 +155,14 @@ void neptune_hip_finalize(void) {
     (void)hipFree(s.reduce_ws);
     s.reduce_ws = nullptr;
   }
+  for (auto& e : g_loops)
+    if (e.exec) {
+      (void)hipGraphExecDestroy(e.exec);
+      (void)hipGraphDestroy(e.graph);
+      e.exec = nullptr;
+      e.graph = nullptr;
+      e.stamp = 0;
+    }
   for (auto& b : s.pool) (void)hipFree(b.p);
   s.pool.clear();
   s.pool_bytes = 0;
@@ -316,6 +349,105 @@ int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const
     case NEPTUNE_HIP_BODY_LAP1D3_F64: return apply_body<builtin::Lap1D3>(g, in, out, s, cfg);
   }
   return NEPTUNE_HIP_EINVAL;
+}
+
+// ---------------------------------------------------------------- hipGraph step loop
+namespace {
+int loop_launch(const LoopKey& k, int from, int to) {
+  const void* ins[NEPTUNE_HIP_MAX_INPUTS];
+  for (int i = 0; i < k.g.num_inputs; ++i) ins[i] = k.in[i];
+  ins[0] = k.fields[from];
+  const neptune_hip_launch_cfg_t* cfg = (k.cfg.kernel || k.cfg.variant >= 0 || k.cfg.chunk || k.cfg.flags) ? &k.cfg : nullptr;
+  return k.fn ? k.fn(&k.g, ins, k.fields[to], (void*)k.stream, cfg)
+              : neptune_hip_apply_builtin(k.body, &k.g, ins, k.fields[to], (void*)k.stream, cfg);
+}
+}  // namespace
+
+int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_apply_geom_t* g, void* const fields[2],
+                          const void* const* in, int64_t steps, void* stream, const neptune_hip_launch_cfg_t* cfg) {
+  if (!g || !fields || !fields[0] || !fields[1] || fields[0] == fields[1] || steps < 0) return NEPTUNE_HIP_EINVAL;
+  if (g->num_inputs < 1 || g->num_inputs > NEPTUNE_HIP_MAX_INPUTS) return NEPTUNE_HIP_EINVAL;
+  if (g->num_inputs > 1 && !in) return NEPTUNE_HIP_EINVAL;
+  ensure_init();
+  LoopKey key;
+  memset(&key, 0, sizeof(key));  // padding too: keys are compared with memcmp
+  key.fn = fn;
+  key.body = fn ? -1 : body;
+  key.g = *g;
+  key.fields[0] = fields[0];
+  key.fields[1] = fields[1];
+  for (int i = 1; i < g->num_inputs; ++i) key.in[i] = in[i];
+  if (cfg) key.cfg = *cfg; else key.cfg.variant = -1;
+  key.stream = as_stream(stream);
+  if (steps == 0) return NEPTUNE_HIP_OK;
+  hipStream_t user = key.stream;
+  if (!user) {
+    // the legacy default stream cannot be captured: run the loop on an internal stream ordered after
+    // everything already queued on the default stream, and order the default stream after the loop
+    if (!g_loop_stream) {
+      NEPTUNE_HIP_CHECK(hipStreamCreateWithFlags(&g_loop_stream, hipStreamNonBlocking));
+      NEPTUNE_HIP_CHECK(hipEventCreateWithFlags(&g_loop_ev[0], hipEventDisableTiming));
+      NEPTUNE_HIP_CHECK(hipEventCreateWithFlags(&g_loop_ev[1], hipEventDisableTiming));
+    }
+    NEPTUNE_HIP_CHECK(hipEventRecord(g_loop_ev[0], nullptr));
+    NEPTUNE_HIP_CHECK(hipStreamWaitEvent(g_loop_stream, g_loop_ev[0], 0));
+    key.stream = g_loop_stream;
+  }
+  auto finish = [&](int rc) {
+    if (!user) {
+      NEPTUNE_HIP_CHECK(hipEventRecord(g_loop_ev[1], g_loop_stream));
+      NEPTUNE_HIP_CHECK(hipStreamWaitEvent(nullptr, g_loop_ev[1], 0));
+    }
+    return rc;
+  };
+
+  // one plain launch first: validates the request (and warms the launcher's one-time queries) outside
+  // of stream capture, and is step 0 of the loop
+  int rc = loop_launch(key, 0, 1);
+  if (rc != NEPTUNE_HIP_OK) return finish(rc);
+  int64_t done = 1;
+  constexpr int kPairs = 8;  // ping-pong pairs per graph: 16 kernel nodes amortise one graph launch
+  if (steps - done >= 2 * kPairs) {
+    RuntimeState& s = rt();
+    std::lock_guard<std::mutex> lk(s.mu);
+    LoopGraph* slot = nullptr;
+    for (auto& e : g_loops)
+      if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) slot = &e;
+    if (!slot) {
+      slot = &g_loops[0];
+      for (auto& e : g_loops)
+        if (e.stamp < slot->stamp) slot = &e;  // least recently used (empty slots have stamp 0)
+      if (slot->exec) {
+        (void)hipGraphExecDestroy(slot->exec);
+        (void)hipGraphDestroy(slot->graph);
+        slot->exec = nullptr;
+        slot->graph = nullptr;
+      }
+      // the pair (1 -> 0, 0 -> 1) leaves the state where it found it, so it can be replayed any number of times
+      NEPTUNE_HIP_CHECK(hipStreamBeginCapture(key.stream, hipStreamCaptureModeRelaxed));
+      int r1 = NEPTUNE_HIP_OK, r2 = NEPTUNE_HIP_OK;
+      for (int p = 0; p < kPairs && r1 == NEPTUNE_HIP_OK && r2 == NEPTUNE_HIP_OK; ++p) {
+        r1 = loop_launch(key, 1, 0);
+        r2 = loop_launch(key, 0, 1);
+      }
+      hipGraph_t graph = nullptr;
+      NEPTUNE_HIP_CHECK(hipStreamEndCapture(key.stream, &graph));
+      if (r1 != NEPTUNE_HIP_OK || r2 != NEPTUNE_HIP_OK || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return finish(r1 != NEPTUNE_HIP_OK ? r1 : (r2 != NEPTUNE_HIP_OK ? r2 : NEPTUNE_HIP_EUNSUPPORTED));
+      }
+      NEPTUNE_HIP_CHECK(hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0));
+      slot->graph = graph;
+      slot->key = key;
+    }
+    slot->stamp = ++g_loop_clock;
+    for (; steps - done >= 2 * kPairs; done += 2 * kPairs) NEPTUNE_HIP_CHECK(hipGraphLaunch(slot->exec, key.stream));
+  }
+  for (; done < steps; ++done) {
+    rc = loop_launch(key, (int)(done % 2), (int)((done + 1) % 2));
+    if (rc != NEPTUNE_HIP_OK) return finish(rc);
+  }
+  return finish(NEPTUNE_HIP_OK);
 }
 
 int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t* g, const void* const* in,

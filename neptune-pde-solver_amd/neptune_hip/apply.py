@@ -57,6 +57,24 @@ def apply_builtin(body, inputs: Sequence[DeviceField], out: DeviceField, bounds:
     _capi.check(rc, "neptune_hip_apply_builtin")
 
 
+def step_loop(body, a: DeviceField, b: DeviceField, bounds: Box, steps: int, others: Sequence[DeviceField] = (),
+              cfg: Optional[_capi.LaunchCfg] = None, stream: Optional[int] = None) -> DeviceField:
+    """`steps` applies in a row, ping-ponging between fields a and b (step 0 reads a); `others` are the fixed
+    inputs 1.. of a multi-input body.  The pair of launches is captured once into a hipGraph and replayed, so small
+    fields are not bound by launch overhead.  Asynchronous; returns the field holding the newest state."""
+    lib = _capi.load()
+    g = geom_for([a] + list(others), b, bounds)
+    fields2 = (C.c_void_p * 2)(a.ptr, b.ptr)
+    ins = _in_array([a] + list(others))
+    st = current_stream_ptr() if stream is None else stream
+    is_entry = hasattr(body, "fn")
+    fn = C.cast(body.fn, C.c_void_p) if is_entry else None
+    rc = lib.neptune_hip_step_loop(fn, -1 if is_entry else body, C.byref(g), fields2, ins, steps, st,
+                                   C.byref(cfg) if cfg is not None else None)
+    _capi.check(rc, "neptune_hip_step_loop")
+    return b if steps % 2 else a
+
+
 def plan_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
                  region: Optional[Box] = None, cfg: Optional[_capi.LaunchCfg] = None) -> int:
     lib = _capi.load()

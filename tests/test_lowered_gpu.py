@@ -332,6 +332,31 @@ def test_geometry_level_entry_tiles_regions_like_the_builtin_bodies(env):
         apply.apply_builtin(entry, [fin], fout, ([1, 2, 2], [18, 16, 254]))
 
 
+def test_step_loop_over_a_lowered_apply(env):
+    """neptune_hip_step_loop with a lowered module's geometry-level entry (function pointer) in place of a built-in
+    body: hipGraph-replayed ping-pong steps == the module's own @entry called step by step"""
+    lowering, torch = env
+    from neptune_hip import apply, fields
+    sys.path.insert(0, str(helpers.REPO / "tools"))
+    import make_stencil_mlir
+    shape = (48, 256)
+    text = make_stencil_mlir.stencil_module("2d5", list(shape))
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("lap2d")
+    u = helpers.hash_field(shape, np.float64, seed=27) * 0.125
+    steps = 25
+    a, b = torch.from_numpy(u).cuda(), torch.zeros(shape, dtype=torch.float64, device="cuda")
+    for _ in range(steps):
+        mod.call("entry", b, a)
+        a, b = b, a
+    want = a.cpu().numpy()
+    fa = fields.DeviceField.from_numpy(u)
+    fb = fields.DeviceField.empty_like(fa)
+    last = apply.step_loop(entry, fa, fb, ([1, 1], [shape[0] - 1, shape[1] - 1]), steps)
+    torch.cuda.synchronize()
+    assert bits_equal(last.numpy(), want), mismatch_report(last.numpy(), want)
+
+
 def test_temporaries_come_from_the_block_pool(env):
     """an apply result that cannot be written into a destination field (here: in-place update, and the rhs
     temp of the two-stage step) is a pooled device block: cached when the call returns, reused by the next

@@ -365,3 +365,26 @@ def test_rank1_fields_on_both_kernels(nh, n, origin, bounds):
         assert bits_equal(fout.numpy(), want), f"n={n} kernel={kern}\n" + mismatch_report(fout.numpy(), want)
     want_plan = nh.capi.KERNEL_MARCH if n >= 128 else nh.capi.KERNEL_DIRECT
     assert nh.apply.plan_builtin(nh.capi.BODY_LAP1D3_F64, [fin], fout, ([bounds[0]], [bounds[1]])) == want_plan
+
+
+@pytest.mark.parametrize("kind,shape,steps", [("2d5", (64, 256), 37), ("3d7", (10, 9, 128), 12), ("2d5", (33, 130), 3), ("3d7", (8, 8, 8), 101)])
+def test_graph_captured_step_loop_equals_chained_launches(nh, kind, shape, steps):
+    """neptune_hip_step_loop: the ping-pong pair captured once into a hipGraph and replayed == `steps` plain launches
+    == the oracle's chained applies; a second call reuses the cached graph; odd/even step counts end in the right field"""
+    body = nh.apply.BODY_BY_NAME[KIND_BODY[kind]]
+    u = helpers.hash_field(shape, KIND_DTYPE[kind], seed=41) * 0.25          # keep 100 Laplacian steps finite
+    want = u
+    for _ in range(steps):
+        want = helpers.oracle_entry(kind, want)
+    bounds = ([1] * len(shape), [n - 1 for n in shape])
+    for rep in range(2):
+        a = nh.fields.DeviceField.from_numpy(u) if rep == 0 else a0
+        a0 = a
+        if rep == 1:
+            a.tensor.copy_(nh.torch.from_numpy(u))
+        b = nh.fields.DeviceField.empty_like(a) if rep == 0 else b0
+        b0 = b
+        last = nh.apply.step_loop(body, a, b, bounds, steps)
+        nh.torch.cuda.synchronize()
+        assert last is (b if steps % 2 else a)
+        assert bits_equal(last.numpy(), want), f"rep {rep}\n" + mismatch_report(last.numpy(), want)
