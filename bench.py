@@ -332,10 +332,10 @@ def main():
             kern_ms = ev_ms / args.steps  # per step on this rank's compute stream (interior + edges + waits)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         plan = nh_apply.plan_builtin(builtin_body, [bufs[0]], bufs[1], sharded.bounds, region=sharded._own_region(), cfg=cfg)
-        auto_variant = 1 if (rank_nd == 3 and points == 27) else 0      # apply_launch.hpp: box stencils take tile 1
-        vidx = cfg.variant if cfg.variant >= 0 else auto_variant
-        if world > 1 and rank_nd == 2 and vidx == 0:
-            vidx = 1                                                   # row-restricted launches use the march form
+        import ctypes as C
+        g_own = nh_apply.geom_for([bufs[0]], bufs[1], sharded.bounds, sharded.interior if (world > 1 and sharded.interior is not None)
+                                  else sharded._own_region())
+        vidx = lib.neptune_hip_apply_builtin_variant(builtin_body, C.byref(g_own), C.byref(cfg))   # the dominant launch's tile
         vname = lib.neptune_hip_march_variant_name(rank_nd, vidx).decode() if plan == _capi.KERNEL_MARCH else ""
         # HBM traffic cannot be counted live (PMC needs rocprofv3): report the per-launch bytes of
         # the matching kernel/shape from the committed separate-pass profile, or null

@@ -232,6 +232,10 @@ int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t *g,
 /* Name of the device kernel (as rocprofv3 lists it, without template arguments) that the
  * plan above launches; pointer valid for the process lifetime. */
 const char *neptune_hip_kernel_name(int kernel);
+/* Which march tile neptune_hip_apply_builtin would use for (body, g, cfg) if it plans the march kernel:
+ * cfg->variant when valid, else the automatic choice (stencil shape, field size, launch region). */
+int neptune_hip_apply_builtin_variant(int body, const neptune_hip_apply_geom_t *g,
+                                      const neptune_hip_launch_cfg_t *cfg);
 /* march tile variants compiled into the library, per field rank (2 or 3) */
 int neptune_hip_march_variant_count(int rank);
 const char *neptune_hip_march_variant_name(int rank, int variant);

@@ -97,29 +97,32 @@ struct MarchVariant {
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, name)
-// The first two variants of each rank are the defaults and are compiled into every lowered
+// The first variants of each rank (NEPTUNE_MARCH*_DEFAULT) are the defaults and are compiled into every lowered
 // module; the others stay in the runtime library for tools/sweep.py and for the parity tests,
 // which run every one of them.  Measured on MI355X (profiles/r01_sweep_report.txt):
 //   rank 3, star  : 0  rj4_wj4_wk2_pf2_lds   (1024^3 fp64 7-point: 6.1 TB/s)
 //   rank 3, box   : 1  rj4_wj8_wk1_pf2_lds   (512^3 fp32 27-point: 5.6 TB/s)
 //   rank 3, star of radius 2 : 2  rj2_wj8_wk1_pf2_lds_jhl  (5 live planes: fewer rows per lane,
 //                      J halo rows only for the centre plane, so the tile fits the register file)
+//   rank 3, small fields     : 3  rj2_wj4_wk1_pf2  (8 rows x one wave span, 4 waves, no LDS: the
+//                      problem is cut into 4-8x more workgroups; 128^3: 10 us instead of 20,
+//                      27-point 256^3: 28 us instead of 46, profiles/r01_size_sweep.txt)
 //   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s), and
 //                   1  wk4_pf4, the march form, for launches restricted to a row range
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)
 #define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
   X(0, 4, 4, 2, true, true, 2, false, true, false, false, "rj4_wj4_wk2_pf2_lds")    \
   X(1, 4, 8, 1, true, true, 2, false, true, false, false, "rj4_wj8_wk1_pf2_lds")    \
-  X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl")
+  X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl") \
+  X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
   X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
   X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(3, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
   X(4, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
-  X(5, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2") \
+  X(5, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
   X(6, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
   X(7, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
   X(8, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
@@ -319,6 +322,40 @@ inline void fill_direct_params(const neptune_hip_apply_geom_t* g, const void* co
   }
 }
 
+// The march tile a launch uses: cfg->variant if valid, else the automatic choice -- box stencils of rank 3
+// take their own default tile, radius-2 stars or several halo inputs (more live rows per lane) the 2-row
+// tile; in 2-D several halo inputs take the march form, whose state is one row per plane (the 4-row
+// tile form spills from three halo inputs on; tools/multihalo_bench.sh, profiles/r01_multihalo.txt).
+template <class T, int RANK, class FP>
+inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_hip_launch_cfg_t* cfg) {
+  int variant = cfg ? cfg->variant : -1;
+  constexpr int kNH = popcount_u(FP::HALO_MASK);
+  constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
+  if (variant < 0 || variant >= march_variant_count(RANK)) {
+    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 1) ? 1 : 0;
+    if constexpr (RANK == 3) {
+      // small fields: if even 16-plane chunks of the default tile give fewer workgroups than CUs (box stencils:
+      // than 4 per CU -- their tile is register-heavy and gains from more, smaller workgroups up to ~400^3),
+      // take the small tile (profiles/r01_size_sweep.txt)
+      const MarchVariant* mv = march_variant(3, variant);
+      const int64_t n1 = g->out_ub[1] - g->out_lb[1], n2 = g->out_ub[2] - g->out_lb[2];
+      const int64_t p0 = g->region_ub[0] - g->region_lb[0];
+      const int64_t tj = (int64_t)mv->RJ * mv->WJ, tk = (int64_t)mv->WK * kWave * (16 / (int64_t)sizeof(T));
+      if (((n1 + tj - 1) / tj) * ((n2 + tk - 1) / tk) * ((p0 + 15) / 16) < (FP::BOX ? 1024 : 256)) variant = 3;
+    }
+  }
+  if constexpr (RANK == 2) {
+    // the rank-2 tile form treats the field as ONE plane: it cannot restrict rows (the march kernel's region
+    // is a plane range) and keeps in-plane offsets in 32 bits, so a row-restricted launch (slab edges) or a
+    // field of 2 GiB and more takes the march form
+    const int64_t field_bytes = (g->out_ub[0] - g->out_lb[0]) * (g->out_ub[1] - g->out_lb[1]) * (int64_t)sizeof(T);
+    if (march_variant(2, variant)->jk &&
+        (g->region_lb[0] != 0 || g->region_ub[0] != g->out_ub[0] - g->out_lb[0] || field_bytes >= 0x7fffffffLL))
+      variant = 1;
+  }
+  return variant;
+}
+
 // the direct kernel on g's region: rows form when all coordinates fit 31 bits (see apply_direct.hpp),
 // else -- or when `flat` asks for it -- the flat form
 template <class Body, class T, int RANK, int NIN>
@@ -366,23 +403,8 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
     MarchParams<T, NIN> P{};
     for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
     P.out = static_cast<T*>(out);
-    // variant < 0 (or no cfg): automatic -- box stencils of rank 3 take their own default tile, and
-    // radius-2 stars or several halo inputs (more live rows per lane) the 2-row tile; in 2-D several
-    // halo inputs take the march form, whose state is one row per plane (the 4-row tile form spills
-    // from three halo inputs on).  Measured: tools/multihalo_bench.sh, profiles/r01_multihalo.txt.
-    int variant = cfg ? cfg->variant : -1;
-    constexpr int kNH = popcount_u(FP::HALO_MASK);
-    constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
-    if (variant < 0 || variant >= march_variant_count(RANK))
-      variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 1) ? 1 : 0;
-    // rank-2 tile form: (d0,d1) -> (J,K), one plane.  It cannot restrict rows (the march kernel's
-    // region is a plane range), so a row-restricted launch takes the default march form.
-    bool jk = RANK == 2 && march_variant(RANK, variant)->jk;
-    const int64_t field_bytes = (g->out_ub[0] - g->out_lb[0]) * (RANK > 1 ? g->out_ub[1] - g->out_lb[1] : 1) * (int64_t)sizeof(T);
-    if (jk && (g->region_lb[0] != 0 || g->region_ub[0] != g->out_ub[0] - g->out_lb[0] || field_bytes >= 0x7fffffffLL)) {
-      jk = false;
-      variant = 1;  // the march form
-    }
+    int variant = pick_march_variant<T, RANK, FP>(g, cfg);
+    const bool jk = RANK == 2 && march_variant(RANK, variant)->jk;  // rank-2 tile form: (d0,d1) -> (J,K), one plane
     auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
       if (jk) { dst[0] = fill; dst[1] = src[0]; dst[2] = src[1]; }
       else to_axes<RANK>(src, dst, fill);

@@ -462,6 +462,17 @@ int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t* g, 
   return NEPTUNE_HIP_EINVAL;
 }
 
+int neptune_hip_apply_builtin_variant(int body, const neptune_hip_apply_geom_t* g, const neptune_hip_launch_cfg_t* cfg) {
+  if (!g) return NEPTUNE_HIP_EINVAL;
+  switch (body) {
+    case NEPTUNE_HIP_BODY_LAP2D5_F64: return pick_march_variant<double, 2, builtin::Lap2D5::FP>(g, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D7_F64: return pick_march_variant<double, 3, builtin::Lap3D7::FP>(g, cfg);
+    case NEPTUNE_HIP_BODY_LAP3D27_F32: return pick_march_variant<float, 3, builtin::Lap3D27::FP>(g, cfg);
+    case NEPTUNE_HIP_BODY_LAP1D3_F64: return pick_march_variant<double, 1, builtin::Lap1D3::FP>(g, cfg);
+  }
+  return NEPTUNE_HIP_EINVAL;
+}
+
 const char* neptune_hip_kernel_name(int kernel) {
   switch (kernel) {
     case NEPTUNE_HIP_KERNEL_DIRECT: return "neptune_apply_direct";
