@@ -44,7 +44,8 @@ def run(workload):
 
 def rows(d, counter):
     out = []
-    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:          # gpurun merges successive runs into the same directory: the newest pass counts
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 if "neptune_apply_march" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
