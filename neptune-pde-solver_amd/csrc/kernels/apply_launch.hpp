@@ -12,6 +12,9 @@
 //     wide, all base pointers are 16-byte aligned, and the region only restricts dim 0.
 //   * otherwise the direct kernel.
 #pragma once
+#include <array>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -392,8 +395,8 @@ inline int launch_direct(const Body& body, const neptune_hip_apply_geom_t* g, co
 }
 
 template <class Body, class T, int RANK, int NIN, class FP>
-inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
-                        hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                             hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
   const int kernel = plan_apply<T, RANK, NIN, FP>(g, in, out, cfg);
   if (kernel < 0) return kernel;
   for (int d = 0; d < RANK; ++d)
@@ -445,6 +448,101 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
   }
 
   return launch_direct<Body, T, RANK, NIN>(body, g, in, out, stream, cfg && (cfg->flags & NEPTUNE_HIP_FLAG_DIRECT_FLAT));
+}
+
+// ---- measured tile choice at first use (NEPTUNE_HIP_TUNE=1) ----------------------------------------------
+// FFTW_MEASURE for applies: the first launch of a (body, geometry) with no explicit configuration times every
+// march tile this translation unit holds (the runtime library: all of them; a lowered module: the defaults,
+// or all with -DNEPTUNE_HIP_FULL_VARIANTS=1) with a few chunk lengths and keeps the fastest for later launches
+// of the same geometry.  Every candidate computes the same bits into `out`, so the timed launches are
+// harmless; they synchronise the stream, which is why this is opt-in and skipped during stream capture.
+inline bool tune_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("NEPTUNE_HIP_TUNE");
+    return e && *e && *e != '0';
+  }();
+  return on;
+}
+
+template <class Body, class T, int RANK, int NIN, class FP>
+inline neptune_hip_launch_cfg_t tune_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                                           hipStream_t stream) {
+  neptune_hip_launch_cfg_t best = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
+  if (plan_apply<T, RANK, NIN, FP>(g, in, out, &best) != NEPTUNE_HIP_KERNEL_MARCH) return best;
+  hipEvent_t e0, e1;
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+  auto time_cfg = [&](const neptune_hip_launch_cfg_t& c) -> float {
+    if (launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c) != NEPTUNE_HIP_OK) return -1.f;
+    NEPTUNE_HIP_CHECK(hipEventRecord(e0, stream));
+    for (int r = 0; r < 3; ++r) launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c);
+    NEPTUNE_HIP_CHECK(hipEventRecord(e1, stream));
+    NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms;
+  };
+  float best_ms = time_cfg(best);
+  const int chunks3[] = {0, 64, 128}, chunks2[] = {0, 32};
+  for (int v = 0; v < march_variant_count(RANK); ++v) {
+    const bool tile2 = RANK == 2 && march_variant(RANK, v)->jk;
+    const int* chunks = RANK == 3 ? chunks3 : chunks2;
+    const int nc = RANK == 3 ? 3 : (RANK == 2 && !tile2 ? 2 : 1);
+    for (int c = 0; c < nc; ++c) {
+      const neptune_hip_launch_cfg_t cand = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
+      const float ms = time_cfg(cand);
+      if (ms > 0 && (best_ms <= 0 || ms < best_ms)) { best_ms = ms; best = cand; }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return best;
+}
+
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                        hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+  const bool free_choice = !cfg || (cfg->kernel == NEPTUNE_HIP_KERNEL_AUTO && cfg->variant < 0 && cfg->chunk == 0 && cfg->flags == 0);
+  if (free_choice && tune_enabled() && g) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs == hipStreamCaptureStatusNone) {
+      // one table per body (this function is instantiated per Body); key: everything of the geometry that the
+      // launcher looks at, plus the 16-byte alignment of the buffers
+      static std::mutex mu;
+      static std::map<std::array<int64_t, 20>, neptune_hip_launch_cfg_t> table;
+      std::array<int64_t, 20> key{};
+      int n = 0;
+      for (int d = 0; d < 3; ++d) {
+        key[n++] = d < RANK ? g->out_ub[d] - g->out_lb[d] : 1;
+        key[n++] = d < RANK ? g->lb[d] - g->out_lb[d] : 0;
+        key[n++] = d < RANK ? g->ub[d] - g->out_lb[d] : 1;
+        key[n++] = d < RANK ? g->region_lb[d] : 0;
+        key[n++] = d < RANK ? g->region_ub[d] : 1;
+      }
+      int64_t align = ((uintptr_t)out % 16 == 0);
+      for (int k = 0; k < NIN; ++k) {
+        align = align * 2 + ((uintptr_t)in[k] % 16 == 0);
+        for (int d = 0; d < RANK; ++d) align = align * 2 + (g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d]);
+      }
+      key[n++] = align;
+      neptune_hip_launch_cfg_t tuned;
+      bool have = false;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = table.find(key);
+        if (it != table.end()) { tuned = it->second; have = true; }
+      }
+      if (!have) {
+        if (geom_validate(g) != NEPTUNE_HIP_OK) return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, cfg);
+        tuned = tune_apply<Body, T, RANK, NIN, FP>(body, g, in, out, stream);
+        std::lock_guard<std::mutex> lk(mu);
+        table[key] = tuned;
+      }
+      return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &tuned);
+    }
+  }
+  return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, cfg);
 }
 
 }  // namespace neptune_hip

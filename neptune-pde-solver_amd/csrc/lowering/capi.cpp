@@ -108,8 +108,11 @@ int neptune_lowering_compile(const char* mlir_text, const char* so_path, const c
   const std::string root = repo_root;
   const std::string libdir = root + "/neptune-pde-solver_amd/lib";
   const std::string log = std::string(so_path) + ".log";
-  // -ffp-contract=off: bodies must evaluate op by op like the reference's FMA-free lowering
-  const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -x hip '" + hip_path +
+  // -ffp-contract=off: bodies must evaluate op by op like the reference's FMA-free lowering.
+  // NEPTUNE_HIP_FULL_VARIANTS=1 compiles every march tile into the module (longer build; for NEPTUNE_HIP_TUNE=1).
+  const char* fullv = std::getenv("NEPTUNE_HIP_FULL_VARIANTS");
+  const std::string defs = (fullv && *fullv && *fullv != '0') ? " -DNEPTUNE_HIP_FULL_VARIANTS=1" : "";
+  const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared" + defs + " -x hip '" + hip_path +
                           "' -I'" + root + "' -L'" + libdir + "' -lneptune_hip -Wl,-rpath,'" + libdir + "' -o '" + so_path +
                           "' > '" + log + "' 2>&1";
   rc = std::system(cmd.c_str());

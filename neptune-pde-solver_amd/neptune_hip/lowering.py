@@ -80,7 +80,10 @@ def cache_dir() -> Path:
 
 
 def module_hash(text: str) -> str:
-    return hashlib.sha256(text.encode("utf-8")).hexdigest()[:16]
+    """cache key: the module text (reference contract, backend.py:26-41: sha256(IR)[:16]); a build with every march
+    tile compiled in (NEPTUNE_HIP_FULL_VARIANTS=1) is a different artefact of the same text"""
+    full = os.environ.get("NEPTUNE_HIP_FULL_VARIANTS", "") not in ("", "0")
+    return hashlib.sha256((text + ("\n// all march tiles" if full else "")).encode("utf-8")).hexdigest()[:16]
 
 
 def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: bool = True) -> "LoweredModule":

@@ -357,6 +357,47 @@ def test_step_loop_over_a_lowered_apply(env):
     assert bits_equal(last.numpy(), want), mismatch_report(last.numpy(), want)
 
 
+def test_first_use_tuning_keeps_the_bits(env, tmp_path):
+    """NEPTUNE_HIP_TUNE=1: the first launch of each (apply, geometry) times the module's tiles and keeps the fastest;
+    results stay bit-exact (every tile computes the same bits), later calls reuse the choice"""
+    script = tmp_path / "tune.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {str(helpers.REPO / 'neptune-pde-solver_amd')!r}); sys.path.insert(0, {str(helpers.REPO / 'tests')!r})
+os.environ["NEPTUNE_CACHE_DIR"] = {str(tmp_path)!r}
+os.environ["NEPTUNE_HIP_TUNE"] = "1"
+import numpy as np, torch, helpers
+from helpers import oracle, bits_equal
+from neptune_hip import lowering, _capi, apply, fields
+sys.path.insert(0, {str(helpers.REPO / 'tools')!r})
+import make_stencil_mlir
+cases = [(make_stencil_mlir.stencil_module("3d7", [20, 18, 256]), (20, 18, 256)),
+         (make_stencil_mlir.stencil_module("2d5", [40, 512]), (40, 512)),
+         ((helpers.FIXTURE_DIR / "apply-3d-13pt.mlir").read_text(), (20, 18, 256))]
+for fixture, (text, shape) in enumerate(cases):
+    mod = lowering.compile_module(text)
+    u = helpers.hash_field(shape, np.float64, seed=33)
+    want = np.zeros_like(u)
+    oracle.Module.parse(text).call("entry", want, u)
+    d_in = torch.from_numpy(u).cuda()
+    for rep in range(3):
+        d_out = torch.zeros(shape, dtype=torch.float64, device="cuda")
+        mod.call("entry", d_out, d_in)
+        assert bits_equal(d_out.cpu().numpy(), want), (fixture, rep)
+# the library's built-in bodies take the same route when no configuration is given
+a = fields.DeviceField.hashed((24, 16, 256), _capi.F64, seed=2)
+b = fields.DeviceField.empty_like(a); c = fields.DeviceField.empty_like(a)
+bounds = ([1, 1, 1], [23, 15, 255])
+apply.apply_builtin(_capi.BODY_LAP3D7_F64, [a], b, bounds)
+apply.apply_builtin(_capi.BODY_LAP3D7_F64, [a], c, bounds, cfg=apply.make_cfg(_capi.KERNEL_DIRECT))
+torch.cuda.synchronize()
+assert apply.count_mismatch(b, c) == 0
+print("TUNE_OK")
+""")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "TUNE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_temporaries_come_from_the_block_pool(env):
     """an apply result that cannot be written into a destination field (here: in-place update, and the rhs
     temp of the two-stage step) is a pooled device block: cached when the call returns, reused by the next
