@@ -337,6 +337,13 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
   if (variant < 0 || variant >= march_variant_count(RANK)) {
     variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 1) ? 1 : 0;
     if constexpr (RANK == 3) {
+      // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
+      // third of the lanes idle) take the one-wave-wide tile with twice the rows (measured +10 % at 320^3-640^3)
+      if (variant == 0) {
+        const int64_t n2 = g->out_ub[2] - g->out_lb[2], span = kWave * (16 / (int64_t)sizeof(T));
+        const int64_t wide = (n2 + 2 * span - 1) / (2 * span) * 2 * span, narrow = (n2 + span - 1) / span * span;
+        if (wide * 20 > narrow * 21) variant = 1;
+      }
       // small fields: if even 16-plane chunks of the default tile give fewer workgroups than CUs (box stencils:
       // than 4 per CU -- their tile is register-heavy and gains from more, smaller workgroups up to ~400^3),
       // take the small tile (profiles/r01_size_sweep.txt)
