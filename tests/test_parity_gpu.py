@@ -276,6 +276,49 @@ def test_full_size_2d_8192(nh):
     assert bits_equal(got, want), mismatch_report(got, want)
 
 
+@pytest.mark.parametrize("kind,shape", [("3d7", (1024, 1024, 1024)), ("3d7", (1025, 513, 1025)), ("3d27", (512, 512, 512)), ("2d5", (8192, 8192)),
+                                        ("2d5", (8193, 4097))])
+def test_full_size_polynomial_fields_every_cell(nh, kind, shape):
+    """size-independent properties checked on EVERY cell of the full-size fields: a Laplacian-type stencil of an
+    affine field with integer coefficients is exactly 0 at every interior cell (all partial sums are integers far
+    below 2^53 / 2^24), of a quadratic field exactly its constant second difference, and the rim is the input --
+    any wrong neighbour, plane, halo row, tile seam, chunk seam or tail cell shows up as a nonzero"""
+    torch = nh.torch
+    body = nh.apply.BODY_BY_NAME[KIND_BODY[kind]]
+    tdt = torch.float64 if KIND_DTYPE[kind] == np.float64 else torch.float32
+    rank = len(shape)
+    coef = [3, 5, 7][:rank]                                    # affine: u = 3 i + 5 j + 7 k  (< 2^15: exact in f32 too)
+    idx = [torch.arange(n, device="cuda", dtype=tdt) for n in shape]
+    bounds = ([1] * rank, [n - 1 for n in shape])
+    inner = tuple(slice(1, -1) for _ in shape)
+    for quadratic in (False, True):
+        if quadratic and tdt == torch.float32:
+            continue                                           # i^2 terms leave the exact f32 integer range at 512
+        u = torch.zeros(shape, dtype=tdt, device="cuda")
+        for d in range(rank):
+            view = [1] * rank
+            view[d] = shape[d]
+            x = idx[d].reshape(view)
+            u += (x * x * (d + 1)) if quadratic else (x * coef[d])
+        fin = nh.fields.DeviceField(tuple([0] * rank), tuple(shape), nh.capi.F64 if tdt == torch.float64 else nh.capi.F32, u)
+        fout = nh.fields.DeviceField.empty_like(fin)
+        fout.tensor.fill_(-1.0)
+        assert nh.apply.plan_builtin(body, [fin], fout, bounds) == nh.capi.KERNEL_MARCH
+        nh.apply.apply_builtin(body, [fin], fout, bounds)
+        torch.cuda.synchronize()
+        out = fout.tensor
+        # second differences of d*(x^2) summed over dims = 2*(1+2+3), times the fixture's dxinv2 (a power of two)
+        scale = {"2d5": 0.125, "3d7": 0.0625, "3d27": 0.015625}[kind]
+        expect = scale * 2.0 * sum(range(1, rank + 1)) if quadratic else 0.0
+        bad = int((out[inner] != expect).sum())
+        assert bad == 0, f"{kind} {shape} quadratic={quadratic}: {bad} interior cells differ from {expect}"
+        rim = torch.ones(shape, dtype=torch.bool, device="cuda")
+        rim[inner] = False
+        assert bool((out[rim] == u[rim]).all()), "copy-through rim differs from input 0"
+        del u, fin, fout, out, rim
+        torch.cuda.empty_cache()
+
+
 def test_config1_1024x1024_fixture_geometry(nh):
     """BASELINE.json configs[0]: apply-2d-5pt.mlir, 1024x1024 f64 (the CPU-runnable case)"""
     u = helpers.hash_field((1024, 1024), np.float64, seed=1)
