@@ -1,56 +1,57 @@
-"""Operator-overloading tracer (mirror of python_frontend/neptune/expr.py:3-58): indexing a temp
-emits neptune_ir.access, + - * emit arith ops on the builder; numbers become arith.constant."""
+"""Tracing values of the DSL.  An `Expr` wraps one SSA value of the module under construction; indexing it
+with stencil offsets emits `neptune_ir.access`, arithmetic between Exprs (or an Expr and a Python number,
+which becomes an `arith.constant`) emits the matching `arith` op through the active builder.
+
+Behavioural counterpart of the reference tracer (python_frontend/neptune/expr.py:20-58: `__getitem__` ->
+access, `+ - *` -> arith); `/` is an extension of this package (the reference has no division)."""
+import numbers
+
 from .core import get_compiler
+
+# Python operator name -> builder method emitting the op
+_ARITH = {"add": "create_arith_add", "sub": "create_arith_sub", "mul": "create_arith_mul", "truediv": "create_arith_div"}
 
 
 class Expr:
+    __slots__ = ("_handle",)
+
     def __init__(self, handle):
         self._handle = handle
 
-    def _get_compiler(self):
-        return get_compiler()
+    @staticmethod
+    def lift(value) -> "Expr":
+        """an Expr as is; a real number as a constant of the element type"""
+        if isinstance(value, Expr):
+            return value
+        if isinstance(value, numbers.Real) and not isinstance(value, bool):
+            return Expr(get_compiler().create_constant(float(value)))
+        raise TypeError(f"cannot use {type(value).__name__} in a stencil expression (expected Expr or a real number)")
 
-    def _as_expr(self, other):
-        if isinstance(other, Expr):
-            return other
-        if isinstance(other, (int, float)):
-            return Expr(self._get_compiler().create_constant(float(other)))
-        raise TypeError(f"Unsupported operand type: {type(other)}")
+    def __getitem__(self, offsets):
+        """u[-1], u[0, 1], ...: the value of this temp at a constant offset from the current point"""
+        if isinstance(offsets, numbers.Integral):
+            offsets = (offsets,)
+        if not isinstance(offsets, (tuple, list)) or not all(isinstance(o, numbers.Integral) for o in offsets):
+            raise TypeError(f"stencil offsets must be integers, got {offsets!r}")
+        return Expr(get_compiler().create_access(self._handle, [int(o) for o in offsets]))
 
-    # u[-1], u[0, 1], ...
-    def __getitem__(self, index):
-        if isinstance(index, int):
-            offsets = [index]
-        elif isinstance(index, (tuple, list)):
-            offsets = list(index)
-        else:
-            raise TypeError(f"Indices must be integers or tuples, got {type(index)}")
-        return Expr(self._get_compiler().create_access(self._handle, offsets))
+    def __repr__(self):
+        return f"Expr({self._handle!r})"
 
-    def __add__(self, other):
-        other = self._as_expr(other)
-        return Expr(self._get_compiler().create_arith_add(self._handle, other._handle))
 
-    def __sub__(self, other):
-        other = self._as_expr(other)
-        return Expr(self._get_compiler().create_arith_sub(self._handle, other._handle))
+def _install_operator(name: str, builder_method: str) -> None:
+    def forward(self, other):
+        rhs = Expr.lift(other)
+        return Expr(getattr(get_compiler(), builder_method)(self._handle, rhs._handle))
 
-    def __mul__(self, other):
-        other = self._as_expr(other)
-        return Expr(self._get_compiler().create_arith_mul(self._handle, other._handle))
+    def reflected(self, other):
+        lhs = Expr.lift(other)
+        return Expr(getattr(get_compiler(), builder_method)(lhs._handle, self._handle))
 
-    def __truediv__(self, other):  # extension: the reference tracer has no division (expr.py:33-58)
-        other = self._as_expr(other)
-        return Expr(self._get_compiler().create_arith_div(self._handle, other._handle))
+    forward.__name__, reflected.__name__ = f"__{name}__", f"__r{name}__"
+    setattr(Expr, forward.__name__, forward)
+    setattr(Expr, reflected.__name__, reflected)
 
-    def __radd__(self, other):
-        return self._as_expr(other) + self
 
-    def __rsub__(self, other):
-        return self._as_expr(other) - self
-
-    def __rmul__(self, other):
-        return self._as_expr(other) * self
-
-    def __rtruediv__(self, other):
-        return self._as_expr(other) / self
+for _name, _method in _ARITH.items():
+    _install_operator(_name, _method)
