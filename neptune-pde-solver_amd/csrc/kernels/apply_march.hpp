@@ -222,7 +222,11 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   static_assert(HAS_HALO || (R0 == 0 && R1 == 0 && R2 == 0), "pointwise footprint must have zero radii");
   // J-halo exchange through LDS needs a vertical neighbour in the workgroup and a J radius that
   // one neighbour can serve
-  constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && R1 <= RJ && HAS_HALO;
+  // ... and the exchange buffers (2 x halo inputs x waves x 2*R1 rows x 1 KiB) must leave room for a second
+  // workgroup per CU (160 KiB LDS): beyond 64 KiB -- three halo inputs of radius 2 on an 8-wave tile -- the
+  // halo rows come from global memory like in the tiles without LDSJ
+  constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && R1 <= RJ && HAS_HALO &&
+                        2 * NHX * WJ * WK * 2 * R1 * kWave * (int)sizeof(V) <= 64 * 1024;
   constexpr int LROWS = LDSJ ? 2 * R1 : 1;
   // [double buffer][halo input][wave][first R1 own rows | last R1 own rows][lane]: 1 KiB per row
   __shared__ V lds_rows[LDSJ ? 2 : 1][LDSJ ? NHX : 1][LDSJ ? WJ * WK : 1][LROWS][LDSJ ? kWave : 1];

@@ -150,6 +150,12 @@ def test_emitted_modules_compile_for_gfx950(tmp_path, monkeypatch):
             assert hasattr(mod.lib, sym)
         again = lowering.compile_module(text)     # second call is a cache hit (same file, no recompile)
         assert again.path == mod.path
+    # the heaviest footprint the march kernel accepts in 2-D (four halo inputs of radius 2) must still fit the
+    # 160 KiB of LDS of a CU -- hipcc rejects a kernel that does not
+    import test_multihalo_gpu as mh
+    shape, elem, nin, acc, margin, _ = mh.CASES["four_radius2_2d_f32"]
+    heavy = lowering.compile_module(mh.module_text(shape, elem, nin, acc, [margin] * 2, [n - margin for n in shape]))
+    assert hasattr(heavy.lib, "resid") and heavy.report["applies"][0]["kernel"] == "march"
 
 
 NORM = '''

@@ -95,6 +95,10 @@ CASES = {
     "swe2d": ((40, 512), "f64", 2, [(0, o) for o in star(2)] + [(1, o) for o in star(2)], 1, "march"),
     "four_halo_inputs_2d": ((24, 256), "f64", 4, [(k, o) for k in range(4) for o in star(2)], 1, "march"),
     "radius2_pair_2d": ((30, 256), "f64", 2, [(0, o) for o in star(2, 2)] + [(1, o) for o in star(2, 2)[1:]], 2, "march"),
+    # three and four halo inputs of radius 2: the LDS exchange of the 8-wave tile would need 192-256 KiB (> 160 KiB of
+    # a CU); the kernel then takes its halo rows from global memory instead (found by tools/soak_fuzz.py, seeds 1038/1044)
+    "three_radius2_2d": ((26, 256), "f64", 3, [(k, o) for k in range(3) for o in star(2, 2)], 2, "march"),
+    "four_radius2_2d_f32": ((22, 512), "f32", 4, [(k, o) for k in range(4) for o in star(2, 2)[:7]], 2, "march"),
     "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
     "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
     # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
