@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 CONSTS = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 3.0, -0.0625, 1.75, 0.3125]
 
 
-def gen_apply(rng, name, rank, elem, shape):
+def gen_apply(rng, name, rank, elem, shape, origin):
     nin = int(rng.integers(1, 4))
     radius = int(rng.choice([1, 1, 2]))
     box = radius == 1 and rank > 1 and rng.random() < 0.35
@@ -84,7 +84,7 @@ def gen_apply(rng, name, rank, elem, shape):
     margin = 2 if radius == 2 else 1
     if rng.random() < 0.6:                      # scf.if on an index argument, with a conditional access
         d = int(rng.integers(0, rank))
-        thr = int(shape[d] // 2)
+        thr = origin[d] + int(shape[d] // 2)
         cnt += 1
         off = tuple(margin if a == d else 0 for a in range(rank))      # in range: taken only for i_d < thr
         L.append(f"%thr{cnt} = arith.constant {thr} : index")
@@ -101,8 +101,8 @@ def gen_apply(rng, name, rank, elem, shape):
         L.append("}")
         acc = f"%v{cnt}"
     L.append(f"neptune_ir.yield {acc} : {elem}")
-    lb = [margin + int(rng.integers(0, 2)) for _ in range(rank)]
-    ub = [n - margin - int(rng.integers(0, 2)) for n in shape]
+    lb = [o + margin + int(rng.integers(0, 2)) for o in origin]
+    ub = [o + n - margin - int(rng.integers(0, 2)) for o, n in zip(origin, shape)]
     tys = ", ".join(["!t"] * nin)
     idx = ", ".join(f"%i{d}: index" for d in range(rank))
     ins = ", ".join(f"%in{k}: !t" for k in range(nin))
@@ -115,21 +115,50 @@ def gen_apply(rng, name, rank, elem, shape):
 
 
 def gen_module(seed):
-    """one module = one field shape and element type, three random opdefs"""
+    """one module = one field box (random logical origin) and element type, three random opdefs and an @entry that
+    composes them: op0 on the loaded inputs, optionally a second operator on its result, a full or sub-box store"""
     rng = np.random.default_rng(seed)
     rank = int(rng.choice([1, 2, 3, 3]))
     elem = str(rng.choice(["f64", "f64", "f32"]))
     vk = 2 if elem == "f64" else 4
     last = int(rng.choice([128, 192, 256, 320])) * (vk // 2) + (int(rng.integers(1, vk)) if rng.random() < 0.5 else 0)
     shape = [int(rng.integers(6, 14)) for _ in range(rank - 1)] + [last]
-    ubs = ", ".join(map(str, shape))
-    head = ['#l = #neptune_ir.location<"cell">', f"#b = #neptune_ir.bounds<lb = [{', '.join(['0'] * rank)}], ub = [{ubs}]>",
-            f"!t = !neptune_ir.temp<element = {elem}, bounds = #b, location = #l>", "module {"]
+    origin = [int(rng.integers(-3, 5)) for _ in range(rank)]
+    lbs = ", ".join(map(str, origin))
+    ubs = ", ".join(str(o + n) for o, n in zip(origin, shape))
+    head = ['#l = #neptune_ir.location<"cell">', f"#b = #neptune_ir.bounds<lb = [{lbs}], ub = [{ubs}]>",
+            f"!t = !neptune_ir.temp<element = {elem}, bounds = #b, location = #l>",
+            f"!f = !neptune_ir.field<element = {elem}, bounds = #b, location = #l>", "module {"]
     ops = []
     for n in range(3):
-        text, nin = gen_apply(rng, f"op{n}", rank, elem, shape)
+        text, nin = gen_apply(rng, f"op{n}", rank, elem, shape, origin)
         head.append(text)
         ops.append((f"op{n}", nin))
+    # @entry(out, in0, in1, in2): y = op0(ins...); optionally y = op_k(y, ins[1:]...); store y to out {bounds?}
+    mr = "x".join("?" * rank) + "x" + elem
+    nmax = max(n for _, n in ops)
+    E = [f"  func.func @entry(%out: memref<{mr}>, " + ", ".join(f"%m{k}: memref<{mr}>" for k in range(nmax)) + f") -> memref<{mr}> {{",
+         f"    %fo = neptune_ir.wrap %out : memref<{mr}> -> !f"]
+    for k in range(nmax):
+        E.append(f"    %f{k} = neptune_ir.wrap %m{k} : memref<{mr}> -> !f")
+        E.append(f"    %t{k} = neptune_ir.load %f{k} : !f -> !t")
+    n0 = ops[0][1]
+    E.append("    %y0 = neptune_ir.apply_nonlinear @op0(" + ", ".join(f"%t{k}" for k in range(n0)) + ") : (" + ", ".join(["!t"] * n0) + ") -> !t")
+    cur = "%y0"
+    if rng.random() < 0.6:
+        which = int(rng.integers(1, 3))
+        nk = ops[which][1]
+        args = [cur] + [f"%t{k}" for k in range(1, nk)]
+        E.append(f"    %y1 = neptune_ir.apply_nonlinear @op{which}(" + ", ".join(args) + ") : (" + ", ".join(["!t"] * nk) + ") -> !t")
+        cur = "%y1"
+    if rng.random() < 0.4:
+        slb = [o + int(rng.integers(0, 3)) for o in origin]
+        sub = [o + n - int(rng.integers(0, 3)) for o, n in zip(origin, shape)]
+        E.append(f"    neptune_ir.store {cur} to %fo {{bounds = #neptune_ir.bounds<lb = [{', '.join(map(str, slb))}], ub = [{', '.join(map(str, sub))}]>}} : !t to !f")
+    else:
+        E.append(f"    neptune_ir.store {cur} to %fo : !t to !f")
+    E += [f"    %res = neptune_ir.unwrap %fo : !f -> memref<{mr}>", f"    func.return %res : memref<{mr}>", "  }"]
+    head.append("\n".join(E))
     head.append("}")
     return "\n".join(head) + "\n", tuple(shape), elem, ops
 
@@ -168,3 +197,20 @@ def test_random_applies_match_the_oracle(env, monkeypatch, seed):
             got = mod.call(name, *d_ins).cpu().numpy()
             assert bits_equal(got, want), f"seed={seed} {name} shape={shape} {elem} kernel={kern[name]} {s}\n" + \
                 mismatch_report(got, want) + "\n" + text
+    # the composed @entry: fresh destination, then in place (destination = input 0), device and host buffers
+    nmax = max(n for _, n in ops)
+    ins = [helpers.hash_field(shape, dt, seed=seed + 11 * k) for k in range(nmax)]
+    for inplace in (False, True):
+        h_ins = [a.copy() for a in ins]
+        h_out = h_ins[0] if inplace else np.full(shape, 9.0, dtype=dt)
+        m.call("entry", h_out, *h_ins)
+        for device in (True, False):
+            for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
+                monkeypatch.delenv(k, raising=False)
+            g_ins = [torch.from_numpy(a.copy()).cuda() if device else a.copy() for a in ins]
+            g_out = g_ins[0] if inplace else (torch.full(shape, 9.0, dtype=g_ins[0].dtype, device="cuda") if device
+                                              else np.full(shape, 9.0, dtype=dt))
+            mod.call("entry", g_out, *g_ins)
+            got = g_out.cpu().numpy() if device else g_out
+            assert bits_equal(got, h_out), f"seed={seed} entry inplace={inplace} device={device} shape={shape} {elem}\n" + \
+                mismatch_report(got, h_out) + "\n" + text

@@ -51,6 +51,23 @@ def main():
                     print(helpers.mismatch_report(got, want))
                     print(text)
                     sys.exit(1)
+        for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
+            os.environ.pop(k, None)
+        nmax = max(n for _, n in ops)
+        ins = [helpers.hash_field(shape, dt, seed=seed + 11 * k) for k in range(nmax)]
+        for inplace in (False, True):                # the composed @entry, fresh destination and in place
+            h_ins = [a.copy() for a in ins]
+            h_out = h_ins[0] if inplace else np.full(shape, 9.0, dtype=dt)
+            m.call("entry", h_out, *h_ins)
+            g_ins = [torch.from_numpy(a.copy()).cuda() for a in ins]
+            g_out = g_ins[0] if inplace else torch.full(shape, 9.0, dtype=g_ins[0].dtype, device="cuda")
+            mod.call("entry", g_out, *g_ins)
+            checks += 1
+            if not helpers.bits_equal(g_out.cpu().numpy(), h_out):
+                print(f"MISMATCH seed={seed} entry inplace={inplace} shape={shape} {elem}")
+                print(helpers.mismatch_report(g_out.cpu().numpy(), h_out))
+                print(text)
+                sys.exit(1)
         print(f"seed {seed}: shape={shape} {elem} ok ({checks} checks, {time.time() - t0:.0f} s)", flush=True)
     print(f"SOAK_FUZZ_OK seeds={first}..{first + count - 1} checks={checks} seconds={time.time() - t0:.0f}")
 
