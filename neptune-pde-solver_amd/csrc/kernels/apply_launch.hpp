@@ -111,7 +111,7 @@ struct MarchVariant {
 //                      problem is cut into 4-8x more workgroups; 128^3: 10 us instead of 20,
 //                      27-point 256^3: 28 us instead of 46, profiles/r01_size_sweep.txt)
 //   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s), and
-//                   1  wk4_pf4, the march form, for launches restricted to a row range
+//                   1  wk4_pf4, the march form (fields of 2 GiB and more, several halo inputs)
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)
 #define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
   X(0, 4, 4, 2, true, true, 2, false, true, false, false, "rj4_wj4_wk2_pf2_lds")    \
@@ -191,7 +191,7 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   P.Kl = P.N2 / VK * VK - VK;
   P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl;
   P.nK = (uint32_t)((P.Ks + tileK - 1) / tileK);
-  P.nJ = (uint32_t)((P.N1 + tileJ - 1) / tileJ);
+  P.nJ = (uint32_t)((P.rJ1 - P.rJ0 + tileJ - 1) / tileJ);
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
   int64_t chunk = chunk_req;
   if (chunk <= 0) {
@@ -355,13 +355,11 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     }
   }
   if constexpr (RANK == 2) {
-    // the rank-2 tile form treats the field as ONE plane: it cannot restrict rows (the march kernel's region
-    // is a plane range) and keeps in-plane offsets in 32 bits, so a row-restricted launch (slab edges) or a
-    // field of 2 GiB and more takes the march form
+    // the rank-2 tile form treats the field as ONE plane and keeps in-plane offsets in 32 bits: a field of
+    // 2 GiB and more takes the march form (row-restricted launches -- slab interiors and edges -- stay on the
+    // tile form: MarchParams::rJ0/rJ1)
     const int64_t field_bytes = (g->out_ub[0] - g->out_lb[0]) * (g->out_ub[1] - g->out_lb[1]) * (int64_t)sizeof(T);
-    if (march_variant(2, variant)->jk &&
-        (g->region_lb[0] != 0 || g->region_ub[0] != g->out_ub[0] - g->out_lb[0] || field_bytes >= 0x7fffffffLL))
-      variant = 1;
+    if (march_variant(2, variant)->jk && field_bytes >= 0x7fffffffLL) variant = 1;
   }
   return variant;
 }
@@ -437,8 +435,11 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
       P.pub[a] = (int32_t)hi;
     }
     axes(g->out_lb, P.olb, 0);
-    if (jk) { P.rI0 = 0; P.rI1 = 1; }
-    else {
+    P.rJ0 = 0; P.rJ1 = P.N1;
+    if (jk) {  // one plane; a launch region restricted along d0 is a row range of it
+      P.rI0 = 0; P.rI1 = 1;
+      P.rJ0 = (int32_t)g->region_lb[0]; P.rJ1 = (int32_t)g->region_ub[0];
+    } else {
       to_axes<RANK>(g->region_lb, rlb, 0);
       to_axes<RANK>(g->region_ub, rub, 1);
       P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];

@@ -51,6 +51,7 @@ struct MarchParams {
   int32_t plb[3], pub[3];  // apply.bounds in result-physical coordinates (lb - out_lb)
   int64_t olb[3];          // result logical origin (only feeds the region's index arguments)
   int32_t rI0, rI1;        // planes this launch is responsible for (result-physical)
+  int32_t rJ0, rJ1;        // rows this launch stores (tiles start at rJ0; the rank-2 tile form's row range)
   int32_t chunk;           // planes per workgroup
   uint32_t nJ, nK;         // tiles along J and K (tiles along I = gridDim.x / (nJ*nK))
 };
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
 
   // All in-plane index math is 32-bit (the host guarantees a plane is < 2 GiB); only the plane
   // base is a 64-bit pointer.  Wave-uniform values live in SGPRs.
-  const int32_t j0 = (int32_t)(jt * (WJ * RJ)) + wj * RJ;              // first own row
+  const int32_t j0 = P.rJ0 + (int32_t)(jt * (WJ * RJ)) + wj * RJ;      // first own row
   const int32_t kw = (int32_t)((kt * WK + wk) * (uint32_t)(kWave * VK));  // first own column
   // Waves whose tile lies outside the field are not retired: every address below is clamped
   // into the field and their stores are predicated off, so they can keep taking part in the
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   static_for<RJ>([&](auto rc) {
     constexpr int r = rc;
     in_j[r] = (j0 + r) >= P.plb[1] && (j0 + r) < P.pub[1];
-    row_ok[r] = (j0 + r) < P.N1;
+    row_ok[r] = (j0 + r) < P.rJ1;
   });
   static_for<VK>([&](auto ec) {
     constexpr int e = ec;
