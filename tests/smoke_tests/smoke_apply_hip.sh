@@ -26,14 +26,14 @@ cat > driver.cpp <<'CPP'
 struct Desc1 { void* allocated; void* aligned; int64_t offset; int64_t sizes[1]; int64_t strides[1]; };
 extern "C" Desc1 entry(void*, void*, int64_t, int64_t, int64_t, void*, void*, int64_t, int64_t, int64_t);
 int main() {
-  constexpr int64_t kCells = 16;
+  constexpr int64_t kCells = 24;
   std::vector<double> dst(kCells, 0.0), src(kCells);
   for (int64_t c = 0; c < kCells; ++c) src[c] = double(c + 1);          // smoke convention: in[i] = i+1, out[i] = 0
   const Desc1 got = entry(dst.data(), dst.data(), 0, kCells, 1, src.data(), src.data(), 0, kCells, 1);
   bool ok = got.aligned == dst.data() && got.sizes[0] == kCells && got.strides[0] == 1 && got.offset == 0;
   const double* x = static_cast<const double*>(got.aligned);
   for (int64_t c = 0; c < got.sizes[0]; ++c) {
-    // 100 * ((u[c-1] - 2 u[c]) + u[c+1]) vanishes on a ramp; the two end cells are copy-through
+    // 0.25 * ((u[c-1] + u[c+1]) - (u[c] + u[c])) vanishes on a ramp; the two end cells are copy-through
     const double expect = (c == 0 || c == kCells - 1) ? double(c + 1) : 0.0;
     std::printf("x[%lld]=%.6f\n", (long long)c, x[c]);
     ok = ok && x[c] == expect;

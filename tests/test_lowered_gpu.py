@@ -449,4 +449,4 @@ def test_smoke_script_in_the_shape_of_the_reference_smoke_apply(tmp_path):
     p = subprocess.run(["bash", str(helpers.REPO / "tests/smoke_tests/smoke_apply_hip.sh")], capture_output=True, text=True,
                        env=dict(__import__("os").environ, WORKDIR=str(tmp_path)))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
-    assert "SMOKE_OK" in p.stdout and "x[1]=0.000000" in p.stdout and "x[15]=16.000000" in p.stdout
+    assert "SMOKE_OK" in p.stdout and "x[1]=0.000000" in p.stdout and "x[23]=24.000000" in p.stdout
