@@ -120,6 +120,16 @@ __host__ __device__ __forceinline__ float hash_f32(int64_t index, uint64_t seed)
   return (float)(h >> 41) * (1.0f / 4194304.0f) - 1.0f;  // 23 bits * 2^-22
 }
 
+// ---- grids beyond 2^32 work-items --------------------------------------------------------------------
+// HIP caps a grid dimension at 2^32 work-items (blocks x lanes), which a one-workgroup-per-256-cells launch
+// over a 2048^3 field exceeds.  Such launches fold their workgroup count into (x, y).
+constexpr uint32_t kMaxGridX = 1u << 22;  // x 256 lanes = 2^30 work-items along x
+inline dim3 grid_for_blocks(int64_t blocks) {
+  if (blocks <= (int64_t)kMaxGridX) return dim3((uint32_t)blocks);
+  return dim3(kMaxGridX, (uint32_t)((blocks + kMaxGridX - 1) / kMaxGridX));
+}
+__device__ __forceinline__ int64_t linear_block() { return (int64_t)blockIdx.y * gridDim.x + blockIdx.x; }
+
 // ---- XCD-aware workgroup id ------------------------------------------------------------
 // Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2).  Remap so that
 // each XCD owns one contiguous run of virtual ids: neighbouring tiles (which share halo

@@ -58,7 +58,7 @@ template <class Body, class T, int RANK, int NIN>
 __global__ __launch_bounds__(256) void neptune_apply_direct(DirectParams<T, NIN> P, Body body) {
   const int64_t eK = P.rub[2] - P.rlb[2], eJ = P.rub[1] - P.rlb[1], eI = P.rub[0] - P.rlb[0];
   const int64_t total = eI * eJ * eK;
-  const int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t flat = linear_block() * blockDim.x + threadIdx.x;
   if (flat >= total) return;
   DirectAcc<T, RANK, NIN> acc{P, {0, 0, 0}};
   const int64_t row = flat / eK;
@@ -138,8 +138,10 @@ struct RowAcc {
 // Needs every extent, shift and row count to fit 31 bits (host-checked); otherwise the flat form runs.
 template <class Body, class T, int RANK, int NIN>
 __global__ __launch_bounds__(256) void neptune_apply_rows(DirectParams<T, NIN> P, Body body, uint32_t nchunk) {
-  const uint32_t row = blockIdx.x / nchunk, c = blockIdx.x - row * nchunk;
+  const int64_t b = linear_block();
   const int32_t eJ = (int32_t)(P.rub[1] - P.rlb[1]), eK = (int32_t)(P.rub[2] - P.rlb[2]);
+  if (b >= (P.rub[0] - P.rlb[0]) * (int64_t)eJ * nchunk) return;  // the folded grid's last row of workgroups
+  const uint32_t row = (uint32_t)(b / nchunk), c = (uint32_t)(b - (int64_t)row * nchunk);
   const int32_t i = (int32_t)(row / (uint32_t)eJ), j = (int32_t)(row - (uint32_t)i * (uint32_t)eJ);
   const int32_t k = (int32_t)c * 256 + (int32_t)threadIdx.x;
   if (k >= eK) return;

@@ -381,7 +381,7 @@ inline int launch_direct(const Body& body, const neptune_hip_apply_geom_t* g, co
     }
     const int64_t nchunk = (eK + 255) / 256;
     if (narrow && rows * nchunk < lim) {
-      hipLaunchKernelGGL((neptune_apply_rows<Body, T, RANK, NIN>), dim3((uint32_t)(rows * nchunk)), dim3(256), 0, stream, P,
+      hipLaunchKernelGGL((neptune_apply_rows<Body, T, RANK, NIN>), grid_for_blocks(rows * nchunk), dim3(256), 0, stream, P,
                          body, (uint32_t)nchunk);
       NEPTUNE_HIP_CHECK(hipGetLastError());
       return NEPTUNE_HIP_OK;
@@ -393,7 +393,7 @@ inline int launch_direct(const Body& body, const neptune_hip_apply_geom_t* g, co
     fprintf(stderr, "[NeptuneRT][HIP] direct grid of %lld workgroups is not launchable\n", (long long)blocks);
     abort();
   }
-  hipLaunchKernelGGL((neptune_apply_direct<Body, T, RANK, NIN>), dim3((uint32_t)blocks), dim3(256), 0, stream, P,
+  hipLaunchKernelGGL((neptune_apply_direct<Body, T, RANK, NIN>), grid_for_blocks(blocks), dim3(256), 0, stream, P,
                      body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;

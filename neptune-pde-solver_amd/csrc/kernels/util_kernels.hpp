@@ -20,7 +20,7 @@ template <class T>
 __global__ __launch_bounds__(256) void neptune_store_box(const T* __restrict__ src, T* __restrict__ dst,
                                                          BoxCopyParams P) {
   const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
-  const int64_t flat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t flat = linear_block() * blockDim.x + threadIdx.x;
   if (flat >= total) return;
   const int64_t row = flat / P.ext[2];
   const int64_t k = flat - row * P.ext[2];

@@ -532,10 +532,10 @@ int neptune_hip_store_box(int dtype, int rank, const void* src, const int64_t* s
   if (blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
   ensure_init();
   if (dtype == NEPTUNE_HIP_F64)
-    hipLaunchKernelGGL(neptune_store_box<double>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(neptune_store_box<double>, grid_for_blocks(blocks), dim3(256), 0, as_stream(stream),
                        (const double*)src, (double*)dst, P);
   else
-    hipLaunchKernelGGL(neptune_store_box<float>, dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(neptune_store_box<float>, grid_for_blocks(blocks), dim3(256), 0, as_stream(stream),
                        (const float*)src, (float*)dst, P);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;

@@ -319,6 +319,30 @@ def test_full_size_polynomial_fields_every_cell(nh, kind, shape):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("form", ["direct", "direct-flat"])
+def test_direct_kernel_beyond_2_pow_32_work_items(nh, form):
+    """one workgroup per 256 cells over 1.2e9 cells is more than 2^32 work-items, which HIP refuses in one grid
+    dimension ("invalid configuration argument", found on a 2048^3 field): such launches fold the workgroup count
+    into (x, y).  Affine integer field -> exactly 0 on every interior cell."""
+    torch = nh.torch
+    shape = (1100, 1000, 1100)
+    u = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    for d, c in enumerate((3, 5, 7)):
+        view = [1, 1, 1]
+        view[d] = shape[d]
+        u += torch.arange(shape[d], device="cuda", dtype=torch.float64).reshape(view) * c
+    fin = nh.fields.DeviceField((0, 0, 0), shape, nh.capi.F64, u)
+    fout = nh.fields.DeviceField.empty_like(fin)
+    fout.tensor.fill_(-1.0)
+    nh.apply.apply_builtin(nh.capi.BODY_LAP3D7_F64, [fin], fout, ([1, 1, 1], [n - 1 for n in shape]), cfg=_kernel_cfg(nh, form))
+    torch.cuda.synchronize()
+    out = fout.tensor
+    assert int((out[1:-1, 1:-1, 1:-1] != 0).sum()) == 0
+    assert bool((out[0] == u[0]).all() and (out[-1] == u[-1]).all() and (out[:, :, -1] == u[:, :, -1]).all())
+    del u, fin, fout, out
+    torch.cuda.empty_cache()
+
+
 def test_config1_1024x1024_fixture_geometry(nh):
     """BASELINE.json configs[0]: apply-2d-5pt.mlir, 1024x1024 f64 (the CPU-runnable case)"""
     u = helpers.hash_field((1024, 1024), np.float64, seed=1)
