@@ -61,3 +61,44 @@ def test_decomposition_geometry():
     assert one.local_shape == (1024, 1024, 1024) and one.regions() == (([0, 0, 0], [1024, 1024, 1024]), [])
     with pytest.raises(ValueError):
         slab.decompose(([0], [3]), 1, 0, 4)
+
+
+def test_slab_geometry_properties():
+    """for random (planes, ranks, radius, origin): the slabs tile the global planes exactly once, ghost planes exist only
+    towards existing neighbours, interior + edges tile each rank's owned planes exactly once, edge planes are precisely
+    those within `radius` of a neighbour, and clipped bounds tile the apply bounds"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 8), st.integers(1, 3), st.integers(-7, 7), st.data())
+    def check(world, radius, origin, data):
+        n0 = data.draw(st.integers(max(world * radius, world), 200))
+        box = ([origin, 0], [origin + n0, 6])
+        slabs = [slab.decompose(box, radius, g, world) for g in range(world)]
+        # owned planes: a partition of [origin, origin + n0), balanced to within one plane
+        assert slabs[0].start == origin and slabs[-1].stop == origin + n0
+        assert all(a.stop == b.start for a, b in zip(slabs, slabs[1:]))
+        sizes = [s.n_own for s in slabs]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= radius
+        lb0 = data.draw(st.integers(origin, origin + n0))
+        ub0 = data.draw(st.integers(lb0, origin + n0))
+        covered = []
+        for s in slabs:
+            assert s.r_lo == (radius if s.rank > 0 else 0) and s.r_hi == (radius if s.rank < world - 1 else 0)
+            assert s.local_lb[0] == s.start - s.r_lo and s.local_ub[0] == s.stop + s.r_hi
+            lo, hi = s.owned_planes()
+            interior, edges = s.regions()
+            planes = []
+            for reg in ([interior] if interior is not None else []) + edges:
+                assert reg[0][1:] == [0] and reg[1][1:] == [6]
+                planes += list(range(reg[0][0], reg[1][0]))
+            assert sorted(planes) == list(range(lo, hi))            # exactly once, nothing outside the owned planes
+            if interior is not None:                                # interior planes never touch a ghost plane
+                assert interior[0][0] >= lo + (radius if s.r_lo else 0)
+                assert interior[1][0] <= hi - (radius if s.r_hi else 0)
+            clb, cub = s.clip_bounds(([lb0, 1], [ub0, 5]))
+            assert clb[1:] == [1] and cub[1:] == [5] and s.start <= clb[0] <= cub[0] <= s.stop or clb[0] == cub[0]
+            covered += list(range(clb[0], cub[0]))
+        assert sorted(covered) == list(range(lb0, ub0))             # the clipped bounds tile apply.bounds
+
+    check()
