@@ -512,43 +512,45 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
                         hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
   const bool free_choice = !cfg || (cfg->kernel == NEPTUNE_HIP_KERNEL_AUTO && cfg->variant < 0 && cfg->chunk == 0 && cfg->flags == 0);
   if (free_choice && tune_enabled() && g) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-    if (cs == hipStreamCaptureStatusNone) {
-      // one table per body (this function is instantiated per Body); key: everything of the geometry that the
-      // launcher looks at, plus the 16-byte alignment of the buffers
-      static std::mutex mu;
-      static std::map<std::array<int64_t, 20>, neptune_hip_launch_cfg_t> table;
-      std::array<int64_t, 20> key{};
-      int n = 0;
-      for (int d = 0; d < 3; ++d) {
-        key[n++] = d < RANK ? g->out_ub[d] - g->out_lb[d] : 1;
-        key[n++] = d < RANK ? g->lb[d] - g->out_lb[d] : 0;
-        key[n++] = d < RANK ? g->ub[d] - g->out_lb[d] : 1;
-        key[n++] = d < RANK ? g->region_lb[d] : 0;
-        key[n++] = d < RANK ? g->region_ub[d] : 1;
-      }
-      int64_t align = ((uintptr_t)out % 16 == 0);
-      for (int k = 0; k < NIN; ++k) {
-        align = align * 2 + ((uintptr_t)in[k] % 16 == 0);
-        for (int d = 0; d < RANK; ++d) align = align * 2 + (g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d]);
-      }
-      key[n++] = align;
-      neptune_hip_launch_cfg_t tuned;
-      bool have = false;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        auto it = table.find(key);
-        if (it != table.end()) { tuned = it->second; have = true; }
-      }
-      if (!have) {
-        if (geom_validate(g) != NEPTUNE_HIP_OK) return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, cfg);
+    // one table per body (this function is instantiated per Body); key: everything of the geometry that the
+    // launcher looks at, plus the 16-byte alignment of the buffers
+    static std::mutex mu;
+    static std::map<std::array<int64_t, 20>, neptune_hip_launch_cfg_t> table;
+    std::array<int64_t, 20> key{};
+    int n = 0;
+    for (int d = 0; d < 3; ++d) {
+      key[n++] = d < RANK ? g->out_ub[d] - g->out_lb[d] : 1;
+      key[n++] = d < RANK ? g->lb[d] - g->out_lb[d] : 0;
+      key[n++] = d < RANK ? g->ub[d] - g->out_lb[d] : 1;
+      key[n++] = d < RANK ? g->region_lb[d] : 0;
+      key[n++] = d < RANK ? g->region_ub[d] : 1;
+    }
+    int64_t align = ((uintptr_t)out % 16 == 0);
+    for (int k = 0; k < NIN; ++k) {
+      align = align * 2 + ((uintptr_t)in[k] % 16 == 0);
+      for (int d = 0; d < RANK; ++d) align = align * 2 + (g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d]);
+    }
+    key[n++] = align;
+    neptune_hip_launch_cfg_t tuned;
+    bool have = false;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = table.find(key);
+      if (it != table.end()) { tuned = it->second; have = true; }
+    }
+    if (!have) {
+      // measuring synchronises the stream: not possible while it is being captured into a graph (the step
+      // loop launches once outside capture first, so its graph still gets the measured choice)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+      if (cs == hipStreamCaptureStatusNone && geom_validate(g) == NEPTUNE_HIP_OK) {
         tuned = tune_apply<Body, T, RANK, NIN, FP>(body, g, in, out, stream);
         std::lock_guard<std::mutex> lk(mu);
         table[key] = tuned;
+        have = true;
       }
-      return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &tuned);
     }
+    if (have) return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &tuned);
   }
   return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, cfg);
 }
