@@ -144,23 +144,55 @@ __global__ __launch_bounds__(256) void neptune_reduce_partial_flat(const T* __re
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }
 
-// sub-box of a buffer: flat index over the box, decoded to buffer coordinates
+// sub-box of a buffer (e.g. the interior of a field): workgroups own contiguous runs of row chunks -- a chunk is
+// 256*VK consecutive cells of one row of the box, VK adjacent cells per lane in one 16-byte load (rows of a sub-box
+// start anywhere: unaligned loads) -- so the (row, chunk) -> (i, j, k) bookkeeping is workgroup-uniform scalar work
+// instead of a 64-bit division per cell.  Four chunks per trip keep their loads in flight together.
 template <class T>
 __global__ __launch_bounds__(256) void neptune_reduce_partial_box(const T* __restrict__ src, ReduceBoxParams P,
                                                                    T* __restrict__ partials) {
+  constexpr int VK = 16 / sizeof(T), ITER = 4;
+  typedef T uvec __attribute__((ext_vector_type(VK), aligned(sizeof(T))));
   __shared__ T lds[4];
-  const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
+  const int64_t cells_per_chunk = 256 * VK;
+  const int64_t nchunk = (P.ext[2] + cells_per_chunk - 1) / cells_per_chunk;
+  const int64_t total = P.ext[0] * P.ext[1] * nchunk;
   const int64_t per = (total + gridDim.x - 1) / gridDim.x;
   const int64_t lo = (int64_t)blockIdx.x * per;
   const int64_t hi = lo + per < total ? lo + per : total;
-  T acc = 0;
-  for (int64_t f = lo + threadIdx.x; f < hi; f += blockDim.x) {
-    const int64_t row = f / P.ext[2];
-    const int64_t k = f - row * P.ext[2];
-    const int64_t j = row % P.ext[1];
-    const int64_t i = row / P.ext[1];
-    acc += src[((i + P.off[0]) * P.shape[1] + (j + P.off[1])) * P.shape[2] + (k + P.off[2])];
+  T part[VK];
+#pragma unroll
+  for (int e = 0; e < VK; ++e) part[e] = 0;
+  for (int64_t rc0 = lo; rc0 < hi; rc0 += ITER) {
+    const int64_t row0 = rc0 / nchunk;
+    int64_t c = rc0 - row0 * nchunk, i = row0 / P.ext[1], j = row0 - i * P.ext[1];
+    T v[ITER][VK];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const bool live = rc0 + it < hi;  // uniform
+      const int64_t k0 = (c * 256 + threadIdx.x) * VK;
+      const T* p = src + ((i + P.off[0]) * P.shape[1] + (j + P.off[1])) * P.shape[2] + (P.off[2] + k0);
+      if (live && k0 + VK <= P.ext[2]) {
+        const uvec x = *reinterpret_cast<const uvec*>(p);
+#pragma unroll
+        for (int e = 0; e < VK; ++e) v[it][e] = x[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VK; ++e) v[it][e] = (live && k0 + e < P.ext[2]) ? p[e] : (T)0;  // the row's last, partial vector
+      }
+      if (live && ++c == nchunk) {
+        c = 0;
+        if (++j == P.ext[1]) { j = 0; ++i; }
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+      for (int e = 0; e < VK; ++e) part[e] += v[it][e];
   }
+  T acc = 0;
+#pragma unroll
+  for (int e = 0; e < VK; ++e) acc += part[e];
   const T r = block_sum(acc, lds);
   if (threadIdx.x == 0) partials[blockIdx.x] = r;
 }

@@ -574,7 +574,13 @@ int neptune_hip_reduce_sum(int dtype, int rank, const void* src, const int64_t* 
   ensure_init();
   RuntimeState& s = rt();
   hipStream_t st = as_stream(stream);
-  const int blocks = (int)((total + 255) / 256 < kReduceBlocks ? (total + 255) / 256 : kReduceBlocks);
+  int blocks = (int)((total + 255) / 256 < kReduceBlocks ? (total + 255) / 256 : kReduceBlocks);
+  if (!whole) {  // box kernel: one unit of work = 4 row chunks of 256 lanes x 16 bytes
+    const int64_t cells = 256 * (dtype == NEPTUNE_HIP_F64 ? 2 : 4);
+    const int64_t last = ext[rank - 1];
+    const int64_t trips = ((total / (last ? last : 1)) * ((last + cells - 1) / cells) + 3) / 4;
+    blocks = (int)(trips < kReduceBlocks ? (trips < 1 ? 1 : trips) : kReduceBlocks);
+  }
   ReduceBoxParams P;
   auto fill = [&](const int64_t* a, int64_t* o, int64_t f) {
     o[0] = o[1] = o[2] = f;

@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, "/root/repo/neptune-pde-solver_amd")
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "neptune-pde-solver_amd"))
 import torch
 from neptune_hip import _capi, apply, fields
 lib = _capi.load(); lib.neptune_hip_init(0)
