@@ -19,16 +19,25 @@ struct BoxCopyParams {
 template <class T>
 __global__ __launch_bounds__(256) void neptune_store_box(const T* __restrict__ src, T* __restrict__ dst,
                                                          BoxCopyParams P) {
-  const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
-  const int64_t flat = linear_block() * blockDim.x + threadIdx.x;
-  if (flat >= total) return;
-  const int64_t row = flat / P.ext[2];
-  const int64_t k = flat - row * P.ext[2];
-  const int64_t j = row % P.ext[1];
-  const int64_t i = row / P.ext[1];
-  const int64_t s = ((i + P.soff[0]) * P.sshape[1] + (j + P.soff[1])) * P.sshape[2] + (k + P.soff[2]);
-  const int64_t d = ((i + P.doff[0]) * P.dshape[1] + (j + P.doff[1])) * P.dshape[2] + (k + P.doff[2]);
-  dst[d] = src[s];
+  // one workgroup = one chunk of 256*VK consecutive cells of one row of the box: the row decode is
+  // workgroup-uniform scalar work, a lane moves VK adjacent cells with one 16-byte load and store (rows of a
+  // sub-box start anywhere in either buffer: unaligned accesses); the row's last, partial vector goes cell by cell
+  constexpr int VK = 16 / sizeof(T);
+  typedef T uvec __attribute__((ext_vector_type(VK), aligned(sizeof(T))));
+  const int64_t nchunk = (P.ext[2] + 256 * VK - 1) / (256 * VK);
+  const int64_t b = linear_block();
+  if (b >= P.ext[0] * P.ext[1] * nchunk) return;
+  const int64_t row = b / nchunk, c = b - row * nchunk;
+  const int64_t i = row / P.ext[1], j = row - i * P.ext[1];
+  const int64_t k0 = (c * 256 + threadIdx.x) * VK;
+  if (k0 >= P.ext[2]) return;
+  const T* s = src + ((i + P.soff[0]) * P.sshape[1] + (j + P.soff[1])) * P.sshape[2] + (k0 + P.soff[2]);
+  T* d = dst + ((i + P.doff[0]) * P.dshape[1] + (j + P.doff[1])) * P.dshape[2] + (k0 + P.doff[2]);
+  if (k0 + VK <= P.ext[2]) {
+    *reinterpret_cast<uvec*>(d) = *reinterpret_cast<const uvec*>(s);
+  } else {
+    for (int e = 0; k0 + e < P.ext[2]; ++e) d[e] = s[e];
+  }
 }
 
 // 16 B per lane streaming copies: the measured HBM ceiling the apply kernels are compared with.

@@ -528,7 +528,9 @@ int neptune_hip_store_box(int dtype, int rank, const void* src, const int64_t* s
   fill(ds, P.dshape, 1);
   const int64_t total = P.ext[0] * P.ext[1] * P.ext[2];
   if (total == 0) return NEPTUNE_HIP_OK;
-  const int64_t blocks = (total + 255) / 256;
+  // one workgroup per chunk of 256 lanes x 16 bytes of one row of the box (see the kernel)
+  const int64_t chunk_cells = 256 * (dtype == NEPTUNE_HIP_F64 ? 2 : 4);
+  const int64_t blocks = P.ext[0] * P.ext[1] * ((P.ext[2] + chunk_cells - 1) / chunk_cells);
   if (blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
   ensure_init();
   if (dtype == NEPTUNE_HIP_F64)
