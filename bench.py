@@ -89,7 +89,7 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
         plane_cells *= n
     if sample_planes <= 0:
         # up to ~1.1e9 cells (the whole 1024^3 field: 3 x 8 GiB of host memory) keeps the CPU leg
-        # (fill + one scalar 3-pass run + 3 fused runs) around 10 s on the GPU node's host
+        # (fill + three scalar 3-pass runs + five fused runs) around 15 s on the GPU node's host
         sample_planes = max(3, min(shape[0], int(1.1e9 // plane_cells)))
     sshape = (sample_planes,) + tuple(shape[1:])
     count = sample_planes * plane_cells
@@ -110,7 +110,7 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
         fn.restype = C.c_int
         fn.argtypes = [C.POINTER(ct), C.POINTER(ct)] + [C.c_int64] * nd + [C.POINTER(C.c_int64)] * 2
         best = None
-        reps = 1 if variant == "entry" else 3
+        reps = 3 if variant == "entry" else 5
         for _ in range(reps):
             t0 = time.perf_counter()
             rc = fn(out.ctypes.data_as(C.POINTER(ct)), u.ctypes.data_as(C.POINTER(ct)),
@@ -125,7 +125,7 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
     return {
         "value": res["entry"][0], "unit": "cell-updates/s", "cores": 1, "kind": "port",
         "sample": f"{dims} slab of the workload (same plane size), faithful restatement of the reference "
-                  f"lowering: malloc + copy-through + scalar loop nest + store copy, {res['entry'][1]:.2f} s",
+                  f"lowering: malloc + copy-through + scalar loop nest + store copy, best of 3 runs, {res['entry'][1]:.2f} s each",
         "fused_all_cores": {"value": res["fused"][0], "cores": threads, "seconds": res["fused"][1]},
         "host_cores": os.cpu_count(),
     }
