@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <fstream>
 #include <sstream>
 
@@ -58,6 +59,21 @@ bool front(const char* text, Module& m, Diag& d) {
   if (!text) { d.fail(0, "null module text"); return false; }
   return parse_module(text, m, d) && verify_module(m, d);
 }
+// Nothing may leave the C ABI as a C++ exception: malformed text that slips past a structural check (an op with
+// fewer types or operands than its kind implies) surfaces as std::out_of_range from a checked access -- report
+// it as a diagnostic like any other rejection.
+template <class F>
+int guarded(char** diag_out, F&& body) {
+  try {
+    return body();
+  } catch (const std::exception& e) {
+    if (diag_out) *diag_out = dup(std::string("malformed module (") + e.what() + ")");
+    return -1;
+  } catch (...) {
+    if (diag_out) *diag_out = dup("malformed module");
+    return -1;
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -67,28 +83,33 @@ const char* neptune_lowering_version(void) { return "neptune-lowering 0.1 (Neptu
 void neptune_lowering_free(char* p) { std::free(p); }
 
 int neptune_lowering_verify(const char* mlir_text, char** diag_out) {
-  Module m;
-  Diag d;
-  const bool ok = front(mlir_text, m, d);
-  if (diag_out) *diag_out = ok ? nullptr : dup(d.message);
-  return ok ? 0 : -1;
+  if (diag_out) *diag_out = nullptr;
+  return guarded(diag_out, [&] {
+    Module m;
+    Diag d;
+    const bool ok = front(mlir_text, m, d);
+    if (diag_out) *diag_out = ok ? nullptr : dup(d.message);
+    return ok ? 0 : -1;
+  });
 }
 
 int neptune_lowering_to_hip(const char* mlir_text, char** source_out, char** report_out, char** diag_out) {
   if (source_out) *source_out = nullptr;
   if (report_out) *report_out = nullptr;
   if (diag_out) *diag_out = nullptr;
-  Module m;
-  Diag d;
-  std::string src;
-  LowerInfo info;
-  if (!front(mlir_text, m, d) || !lower_to_hip(m, src, info, d)) {
-    if (diag_out) *diag_out = dup(d.message);
-    return -1;
-  }
-  if (source_out) *source_out = dup(src);
-  if (report_out) *report_out = dup(report_json(info));
-  return 0;
+  return guarded(diag_out, [&] {
+    Module m;
+    Diag d;
+    std::string src;
+    LowerInfo info;
+    if (!front(mlir_text, m, d) || !lower_to_hip(m, src, info, d)) {
+      if (diag_out) *diag_out = dup(d.message);
+      return -1;
+    }
+    if (source_out) *source_out = dup(src);
+    if (report_out) *report_out = dup(report_json(info));
+    return 0;
+  });
 }
 
 int neptune_lowering_compile(const char* mlir_text, const char* so_path, const char* repo_root, const char* hipcc,

@@ -64,6 +64,10 @@ int main(int argc, char** argv) {
   }
   const std::string text = ss.str();
   char *diag = nullptr, *src = nullptr, *rep = nullptr;
+  struct Release {  // the library hands out malloc'ed strings (include/neptune_lowering.h)
+    char *&a, *&b, *&c;
+    ~Release() { neptune_lowering_free(a); neptune_lowering_free(b); neptune_lowering_free(c); }
+  } release{diag, src, rep};
   if (verify_only && !to_hip) {
     if (neptune_lowering_verify(text.c_str(), &diag) != 0) { std::fprintf(stderr, "%s: error: %s\n", in.c_str(), diag); return 1; }
     return 0;

@@ -141,11 +141,22 @@ struct Parser {
     return false;
   }
   bool ok() const { return diag.ok; }
+  // loop condition of every delimited list: false once `close` has been consumed, on an earlier error, or --
+  // with a diagnostic -- at the end of the input (a truncated file must not spin here)
+  bool until(const char* close) {
+    if (!ok()) return false;
+    if (accept(close)) return false;
+    if (peek().kind == Tk::Eof) {
+      diag.fail(peek().line, std::string("unexpected end of input, expected '") + close + "'");
+      return false;
+    }
+    return true;
+  }
   bool is_value(size_t k = 0) const { return peek(k).kind == Tk::Id && peek(k).text[0] == '%'; }
 
   bool parse_int_list(std::vector<int64_t>& v) {
     if (!expect("[")) return false;
-    while (ok() && !accept("]")) {
+    while (until("]")) {
       if (peek().kind != Tk::Num) { diag.fail(peek().line, "expected integer, got '" + peek().text + "'"); return false; }
       v.push_back(std::strtoll(next().text.c_str(), nullptr, 0));
       accept(",");
@@ -155,7 +166,7 @@ struct Parser {
   bool parse_bounds_body(Bounds& b) {  // after '#neptune_ir.bounds': `<` `lb` `=` $lb `,` `ub` `=` $ub `>`
     if (!expect("<")) return false;
     bool has_lb = false, has_ub = false;
-    while (ok() && !accept(">")) {
+    while (until(">")) {
       std::string key = next().text;
       if (!expect("=")) return false;
       if (key == "lb") { has_lb = true; if (!parse_int_list(b.lb)) return false; }
@@ -197,7 +208,7 @@ struct Parser {
     if (k.text == "true" || k.text == "false") { a.kind = AttrValue::Bool; a.b = next().text == "true"; return true; }
     if (k.text == "[") {  // generic array attribute: parsed and dropped
       next();
-      while (ok() && !accept("]")) { AttrValue e; if (!parse_attr_value(e)) return false; accept(","); }
+      while (until("]")) { AttrValue e; if (!parse_attr_value(e)) return false; accept(","); }
       a.kind = AttrValue::Unit;
       return ok();
     }
@@ -206,7 +217,7 @@ struct Parser {
   }
   bool parse_attr_dict(std::map<std::string, AttrValue>& d) {
     if (!expect("{")) return false;
-    while (ok() && !accept("}")) {
+    while (until("}")) {
       std::string key = next().text;
       AttrValue v;
       if (accept("=")) { if (!parse_attr_value(v)) return false; }
@@ -246,7 +257,7 @@ struct Parser {
       ty.kind = k.text == "!neptune_ir.temp" ? TypeKind::Temp : TypeKind::Field;
       if (!expect("<")) return false;
       bool has_b = false;
-      while (ok() && !accept(">")) {
+      while (until(">")) {
         std::string key = next().text;
         if (!expect("=")) return false;
         if (key == "element") ty.elem = next().text;
@@ -270,7 +281,7 @@ struct Parser {
   }
   bool parse_type_list_parens(std::vector<Type>& v) {
     if (!expect("(")) return false;
-    while (ok() && !accept(")")) { Type ty; if (!parse_type(ty)) return false; v.push_back(ty); accept(","); }
+    while (until(")")) { Type ty; if (!parse_type(ty)) return false; v.push_back(ty); accept(","); }
     return ok();
   }
   bool parse_result_types(std::vector<Type>& v) {
@@ -288,7 +299,7 @@ struct Parser {
     if (peek().kind == Tk::Id && peek().text[0] == '^') {
       next();
       if (accept("(")) {
-        while (ok() && !accept(")")) {
+        while (until(")")) {
           BlockArg a;
           a.name = next().text;
           if (!expect(":") || !parse_type(a.type)) return false;
@@ -301,7 +312,7 @@ struct Parser {
     return ok();
   }
   bool parse_ops_until_close(Block& b) {
-    while (ok() && !accept("}")) {
+    while (until("}")) {
       if (peek().kind == Tk::Eof) { diag.fail(peek().line, "unexpected end of input inside a region"); return false; }
       auto op = std::make_unique<Op>();
       if (!parse_op(*op)) return false;
@@ -517,7 +528,7 @@ struct Parser {
       f->name = next().text.substr(1);
       f->kind = FuncKind::Func;
       if (!expect("(")) return false;
-      while (ok() && !accept(")")) {
+      while (until(")")) {
         BlockArg a;
         a.name = next().text;
         if (!expect(":") || !parse_type(a.type)) return false;
@@ -567,7 +578,7 @@ struct Parser {
         if (peek().kind == Tk::Id && peek().text[0] == '@') next();
         if (accept("attributes")) { std::map<std::string, AttrValue> d; if (!parse_attr_dict(d)) return false; }
         if (!expect("{")) return false;
-        while (ok() && !accept("}")) {
+        while (until("}")) {
           if (peek().kind == Tk::Eof) { diag.fail(peek().line, "unexpected end of input inside module"); return false; }
           // stray module-level solver ops (the reference's Python builder can leave e.g. an
           // assemble_matrix there): nothing to lower, skip them

@@ -262,3 +262,19 @@ def test_every_apply_gets_a_geometry_level_entry():
     # applies folded into a reduce have no kernel of their own, hence no entry
     _, rep2 = lowering.to_hip(NORM.format(n0=6, n1=8, m0=5, m1=7))
     assert rep2["applies"][0]["geom_symbol"] == ""
+
+
+def test_front_end_survives_mutated_inputs():
+    """truncated / spliced / flipped / number-swapped versions of every fixture and of random generator modules: neptune-opt may
+    accept or reject them but must terminate with exit code 0 or 1 (tools/fuzz_frontend.py; its sanitizer build found a
+    parser loop that never ended on a truncated attribute dictionary and uncaught range errors on ops cut short)"""
+    import sys
+    sys.path.insert(0, str(helpers.REPO / "tools"))
+    import fuzz_frontend
+    originals, mutants, codes, findings = fuzz_frontend.run(NEPTUNE_OPT, mutants_per_input=4, seed=2, timeout=20.0)
+    assert originals >= 40 and mutants == 4 * originals
+    assert not findings, findings[0][:4]
+    assert set(codes) <= {0, 1}
+    truncated = "module {\n  func.func @f(%a: memref<?xf64>) -> memref<?xf64> attributes {"
+    with pytest.raises(lowering.LoweringError, match="unexpected end of input"):
+        lowering.verify(truncated)
