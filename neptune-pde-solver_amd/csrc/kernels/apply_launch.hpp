@@ -110,7 +110,8 @@ struct MarchVariant {
 //   rank 3, small fields     : 3  rj2_wj4_wk1_pf2  (8 rows x one wave span, 4 waves, no LDS: the
 //                      problem is cut into 4-8x more workgroups; 128^3: 10 us instead of 20,
 //                      27-point 256^3: 28 us instead of 46, profiles/r01_size_sweep.txt)
-//   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s), and
+//   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s),
+//                   2  tile_rj4_wj4_wk1      (two halo inputs: 5.6 TB/s against 4.9 on the march form), and
 //                   1  wk4_pf4, the march form (fields of 2 GiB and more, several halo inputs)
 // X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)
 #define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
@@ -120,7 +121,8 @@ struct MarchVariant {
   X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
   X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
-  X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")
+  X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")             \
+  X(2, 4, 4, 1, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk1")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
@@ -149,7 +151,6 @@ struct MarchVariant {
   X(26, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
-  X(2, 1, 1, 4, false, false, 1, false, false, false, false, "wk4_pf1_shfl_plainst") \
   X(3, 1, 1, 4, true, true, 2, false, false, false, false, "wk4_pf2")  \
   X(4, 1, 1, 1, true, true, 4, false, false, false, false, "wk1_pf4")  \
   X(5, 1, 1, 4, true, true, 8, false, false, false, false, "wk4_pf8")  \
@@ -159,7 +160,7 @@ struct MarchVariant {
   X(9, 4, 4, 2, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk2")    \
   X(10, 4, 8, 2, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk2")   \
   X(11, 8, 4, 1, true, true, 1, false, true, true, false, "tile_rj8_wj4_wk1")   \
-  X(12, 4, 4, 1, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk1")   \
+  X(12, 1, 1, 4, false, false, 1, false, false, false, false, "wk4_pf1_shfl_plainst") \
   X(13, 4, 8, 1, false, false, 1, false, true, true, false, "tile_rj4_wj8_wk1_shfl_plainst")
 #else
 #define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
@@ -170,6 +171,18 @@ struct MarchVariant {
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
+// the tables are indexed by position, the launch switch by the X index: they must agree
+#define NEPTUNE_MV_IDX(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name) idx,
+constexpr int kMarch3Idx[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_IDX)};
+constexpr int kMarch2Idx[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_IDX)};
+#undef NEPTUNE_MV_IDX
+template <int N>
+constexpr bool consecutive_from_zero(const int (&a)[N]) {
+  for (int i = 0; i < N; ++i)
+    if (a[i] != i) return false;
+  return true;
+}
+static_assert(consecutive_from_zero(kMarch3Idx) && consecutive_from_zero(kMarch2Idx), "march variant lists must be listed in index order");
 constexpr int kNumMarch3 = sizeof(kMarch3) / sizeof(kMarch3[0]);
 constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
 
@@ -335,7 +348,7 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
   constexpr int kNH = popcount_u(FP::HALO_MASK);
   constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
   if (variant < 0 || variant >= march_variant_count(RANK)) {
-    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 1) ? 1 : 0;
+    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 2) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
       // third of the lanes idle) take the one-wave-wide tile with twice the rows (measured +10 % at 320^3-640^3)
