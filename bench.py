@@ -215,14 +215,12 @@ def main():
         del probe
     # Halo transport: RCCL send/recv between device buffers.  RCCL builds its point-to-point channels on
     # first use (seconds): do that here, outside every timed or counted step.  If that first exchange
-    # fails on some rank (a node whose peer-to-point path is unusable), ALL ranks switch -- agreed over a
-    # gloo control group -- to staging the planes through host memory: slower, still correct, and
-    # reported as config.halo_transport.
+    # fails on some rank (a node whose peer-to-peer path is unusable), ALL ranks switch to staging the planes
+    # through host memory over a gloo group: slower, still correct, and reported as config.halo_transport.
     halo_group, transport = None, ("rccl" if world > 1 else "none")
     if world > 1 and args.rehearse_on_one_gpu:
         transport = "gloo-host-staged (rehearsal)"
     elif world > 1 and emu is None:
-        ctrl = dist.new_group(backend="gloo")
         ok = 1
         try:
             for w in slab_mod.exchange_halos(sl, bufs[0].tensor):
@@ -232,10 +230,12 @@ def main():
             ok = 0
             print(f"[bench] rank {rank}: RCCL halo exchange failed ({type(e).__name__}: {e}); proposing host staging",
                   file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ctrl)
+        # agree over RCCL's collectives (they do not use the point-to-point channels); the gloo group of the fallback
+        # is only created when it is needed -- gloo announces itself on stdout, which belongs to the one JSON line
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            halo_group, transport = ctrl, "gloo-host-staged (RCCL point-to-point failed)"
+            halo_group, transport = dist.new_group(backend="gloo"), "gloo-host-staged (RCCL point-to-point failed)"
     op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=halo_group)
     sharded = op
     stream_ptr = fields.current_stream_ptr()
