@@ -32,5 +32,16 @@ def apply_linear(symbol: str, *inputs: Expr) -> Expr:
     return Expr(get_compiler().create_apply_linear(symbol, [i._handle for i in inputs]))
 
 
+def reduce_sum(value: Expr, bounds=None) -> Expr:
+    """sum of a temp over its box (or the sub-box bounds=(lb, ub)); `reduce_sum(apply(...)(kernel))` is one kernel"""
+    lb, ub = bounds if bounds is not None else (None, None)
+    return Expr(get_compiler().create_reduce_sum(value._handle, lb, ub))
+
+
+def time_advance(state: Expr, dt: float, rhs: str) -> Expr:
+    """explicit Euler step state + dt * rhs(state); `rhs` is the symbol a linear_op_def returned"""
+    return Expr(get_compiler().create_time_advance_explicit(state._handle, dt, rhs))
+
+
 __all__ = ["Context", "get_compiler", "reset", "Expr", "apply", "stencil", "linear_op_def", "assemble_matrix",
-           "solve_linear", "jit_compile", "jit_class", "wrap", "load", "store", "unwrap", "apply_linear"]
+           "solve_linear", "jit_compile", "jit_class", "wrap", "load", "store", "unwrap", "apply_linear", "reduce_sum", "time_advance"]

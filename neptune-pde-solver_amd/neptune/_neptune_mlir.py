@@ -219,6 +219,31 @@ class Compiler:
         self._emit(f"{name} = neptune_ir.apply_linear @{symbol}({', '.join(v.name for v in inputs)}) : ({tys}) -> {res_t.text()}")
         return Value(name, res_t)
 
+    # ---- extensions on the lowered path: reduce and explicit time stepping -----------------
+    def create_reduce_sum(self, temp: Value, lb=None, ub=None) -> Value:
+        """neptune_ir.reduce %t [in bounds] {kind = "sum"} (NeptuneIROps.td:272-299): a scalar of the element type.
+        Of a single-use apply result it lowers to ONE kernel (dot products, norms)."""
+        if temp.type.kind != "temp":
+            raise TypeError("create_reduce_sum needs a temp value")
+        name = self._fresh("s")
+        where = ""
+        if lb is not None:
+            where = " in #neptune_ir.bounds<lb = [%s], ub = [%s]>" % (", ".join(map(str, lb)), ", ".join(map(str, ub)))
+        self._emit(f'{name} = neptune_ir.reduce {temp.name}{where} {{kind = "sum"}} : {temp.type.text()} -> {temp.type.elem}')
+        return Value(name, _Type("scalar", temp.type.elem))
+
+    def create_time_advance_explicit(self, state: Value, dt: float, rhs_symbol: str) -> Value:
+        """neptune_ir.time_advance %state, %dt {method = 0, rhs = @symbol}: state + dt * rhs(state), one fused kernel
+        when @symbol is a single apply of the state (NeptuneIROps.td:745-775; explicit form of HighLevelConvertion.cpp:77-120)"""
+        if state.type.kind != "temp" or state.type.elem != "f64":
+            raise TypeError("explicit time_advance needs an f64 temp state (dt is f64 in the op definition)")
+        dtv = self._fresh("dt")
+        self._emit(f"{dtv} = arith.constant {float(dt)!r} : f64")
+        name = self._fresh("u")
+        self._emit(f"{name} = neptune_ir.time_advance {state.name}, {dtv} {{method = 0 : i32, rhs = @{rhs_symbol}}} "
+                   f": {state.type.text()}, f64 -> {state.type.text()}")
+        return Value(name, state.type)
+
     # ---- solver surface: emitted textually, never lowered here (host PETSc path) -----------
     def create_assemble_matrix(self, op_symbol: str) -> Value:
         name = self._fresh("A")

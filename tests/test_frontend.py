@@ -88,6 +88,51 @@ def test_dsl_built_module_means_what_it_says():
     assert bits_equal(out, want)
 
 
+def test_dsl_reduce_and_explicit_time_step():
+    """extensions of the Python face onto the lowered path: neptune.reduce_sum (a dot product written as
+    reduce(apply(a*b)) lowers to one kernel) and neptune.time_advance (explicit Euler, fused with its rhs operator)"""
+    n0, n1 = 10, 16
+    box = ([0, 0], [n0, n1])
+
+    @nep.linear_op_def(bounds=box, location="cell", apply_bounds=([1, 1], [n0 - 1, n1 - 1]))
+    def lap(u):
+        return u[-1, 0] + u[1, 0] + u[0, -1] + u[0, 1] - 4.0 * u[0, 0]
+
+    c = nep.get_compiler()
+    c.start_function("dot", [("memref", 2), ("memref", 2)])
+    a, b = (nep.load(nep.wrap(nep.Expr(c.get_function_arg(i)), box)) for i in range(2))
+
+    @nep.apply(inputs=[a, b], bounds=box)
+    def prod(x, y):
+        return x[0, 0] * y[0, 0]
+
+    c.create_return(nep.reduce_sum(prod, bounds=([1, 1], [n0 - 1, n1 - 1]))._handle)
+    c.end_function()
+    c.start_function("step", [("memref", 2), ("memref", 2)])
+    fout, fin = nep.wrap(nep.Expr(c.get_function_arg(0)), box), nep.wrap(nep.Expr(c.get_function_arg(1)), box)
+    nep.store(nep.time_advance(nep.load(fin), 0.125, lap), fout)
+    c.create_return(nep.unwrap(fout)._handle)
+    c.end_function()
+    text = c.dump()
+    lowering.verify(text)
+    src, report = lowering.to_hip(text)
+    assert report["lowered"] == ["lap", "dot", "step"]
+    kinds = {x["function"]: (x["kernel"], x["inputs"]) for x in report["applies"]}
+    assert kinds["dot"] == ("reduce", 2) and kinds["step"] == ("march", 1)          # fused reduce; fused Euler step
+    u = helpers.hash_field((n0, n1), np.float64, seed=7)
+    v = helpers.hash_field((n0, n1), np.float64, seed=8)
+    m = oracle.Module.parse(text)
+    acc = 0.0
+    for x in (u[1:-1, 1:-1] * v[1:-1, 1:-1]).ravel():
+        acc += x
+    assert m.call("dot", u, v) == acc
+    out = np.zeros_like(u)
+    m.call("step", out, u)
+    i, j = 4, 9
+    lap_ij = (((u[i - 1, j] + u[i + 1, j]) + u[i, j - 1]) + u[i, j + 1]) - 4.0 * u[i, j]
+    assert out[i, j] == u[i, j] + 0.125 * lap_ij and out[0, 3] == u[0, 3] + 0.125 * u[0, 3]
+
+
 def test_apply_decorator_and_reverse_operators():
     c = nep.get_compiler()
     c.start_function("f", [("temp", [0], [8])])

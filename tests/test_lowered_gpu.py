@@ -215,6 +215,51 @@ def test_python_dsl_jit_class_end_to_end(env):
     assert bits_equal(d_out.cpu().numpy(), want)
 
 
+def test_python_dsl_dot_product_and_time_step_on_the_device(env):
+    """neptune.reduce_sum / neptune.time_advance (Python face of the fused kernels) built with the DSL, compiled through
+    neptune.jit_compile and run on device-resident arrays"""
+    lowering, torch = env
+    import neptune as nep
+    nep.reset()
+    n0, n1 = 24, 256
+    box = ([0, 0], [n0, n1])
+
+    @nep.linear_op_def(bounds=box, location="cell", apply_bounds=([1, 1], [n0 - 1, n1 - 1]))
+    def lap(u):
+        return u[-1, 0] + u[1, 0] + u[0, -1] + u[0, 1] - 4.0 * u[0, 0]
+
+    c = nep.get_compiler()
+    c.start_function("dot", [("memref", 2), ("memref", 2)])
+    a, b = (nep.load(nep.wrap(nep.Expr(c.get_function_arg(i)), box)) for i in range(2))
+
+    @nep.apply(inputs=[a, b], bounds=box)
+    def prod(x, y):
+        return x[0, 0] * y[0, 0]
+
+    c.create_return(nep.reduce_sum(prod)._handle)
+    c.end_function()
+    c.start_function("step", [("memref", 2), ("memref", 2)])
+    fout, fin = nep.wrap(nep.Expr(c.get_function_arg(0)), box), nep.wrap(nep.Expr(c.get_function_arg(1)), box)
+    nep.store(nep.time_advance(nep.load(fin), 0.125, lap), fout)
+    c.create_return(nep.unwrap(fout)._handle)
+    c.end_function()
+    text = c.dump()
+    mod = nep.jit_compile(c)
+    nep.reset()
+    m = oracle.Module.parse(text)
+    u = helpers.hash_field((n0, n1), np.float64, seed=3)
+    v = helpers.hash_field((n0, n1), np.float64, seed=4)
+    du, dv = torch.from_numpy(u).cuda(), torch.from_numpy(v).cuda()
+    got = mod.call("dot", du, dv)
+    want = float(m.call("dot", u, v))
+    assert abs(got - want) <= 2 * u.size * np.finfo(np.float64).eps * float(np.abs(u * v).sum())
+    out = torch.zeros_like(du)
+    mod.call("step", out, du)
+    ref = np.zeros_like(u)
+    m.call("step", ref, u)
+    assert bits_equal(out.cpu().numpy(), ref)
+
+
 def test_c_caller_in_the_style_of_the_petsc_matmult_thunk(env, tmp_path):
     """a plain C program looks the lowered operator up with dlsym(RTLD_DEFAULT), calls it with a host
     array and free()s the result -- the three things LinSolverCtx::MatMultThunk does
