@@ -39,6 +39,22 @@ __host__ __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
 __host__ __device__ __forceinline__ double absf(double x) { return ::fabs(x); }
 __host__ __device__ __forceinline__ float absf(float x) { return ::fabsf(x); }
 
+// Elementary functions (math.exp / log / sin / cos / tanh / powf).  Unlike everything above these are NOT exactly
+// specified: the reference lowers them to libm calls (math-to-llvm -> intrinsics -> libm on the CPU), this backend
+// to the device math library; both are accurate to about an ulp, not correctly rounded, so results agree to a few
+// ulp instead of bit for bit.  The lowering report flags bodies that use them ("exact": false).
+#define NEPTUNE_ELEMENTARY(name, f64fn, f32fn)                                         \
+  __host__ __device__ __forceinline__ double name(double x) { return f64fn(x); }       \
+  __host__ __device__ __forceinline__ float name(float x) { return f32fn(x); }
+NEPTUNE_ELEMENTARY(exp, ::exp, ::expf)
+NEPTUNE_ELEMENTARY(log, ::log, ::logf)
+NEPTUNE_ELEMENTARY(sin, ::sin, ::sinf)
+NEPTUNE_ELEMENTARY(cos, ::cos, ::cosf)
+NEPTUNE_ELEMENTARY(tanh, ::tanh, ::tanhf)
+#undef NEPTUNE_ELEMENTARY
+__host__ __device__ __forceinline__ double powf(double a, double b) { return ::pow(a, b); }
+__host__ __device__ __forceinline__ float powf(float a, float b) { return ::powf(a, b); }
+
 // Explicit time_advance: out = s + dt * k with the two roundings the reference's lowering produces
 // (arith.mulf then arith.addf, HighLevelConvertion.cpp:109-110).  Input 0 = state, input 1 = rhs(state).
 template <class T, int RANK>

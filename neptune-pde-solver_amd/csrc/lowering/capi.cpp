@@ -50,7 +50,7 @@ std::string report_json(const LowerInfo& info) {
       << ", \"inputs\": " << a.num_inputs << ", \"kernel\": \"" << (a.fused_reduce ? "reduce" : (a.march ? "march" : "direct"))
       << "\", \"shape\": \""
       << (a.halo_input < 0 ? "pointwise" : (a.box ? "box" : "star")) << "\", \"elem\": \"" << a.elem << "\", \"halo0\": " << a.halo0
-      << ", \"geom_symbol\": \"" << a.geom_symbol << "\"}";
+      << ", \"geom_symbol\": \"" << a.geom_symbol << "\", \"exact\": " << (a.exact ? "true" : "false") << "}";
   }
   o << "]}";
   return o.str();

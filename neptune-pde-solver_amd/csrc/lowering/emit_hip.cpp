@@ -90,6 +90,7 @@ struct Footprint {
   int halo_inputs = 0;
   int R[3] = {0, 0, 0};  // shared radii on the kernel's (I,J,K) axes
   bool march_ok = true;
+  bool exact = true;     // no elementary functions in the body
 };
 
 struct Emitter {
@@ -97,6 +98,7 @@ struct Emitter {
   Diag& diag;
   LowerInfo& info;
   std::ostringstream bodies, funcs, geom_entries;
+  bool saw_elementary = false;  // set by emit_op when it emits exp/log/sin/cos/tanh/powf
   int box_counter = 0;
   std::ostringstream consts;
   Emitter(const Module& mm, Diag& d, LowerInfo& i) : m(mm), diag(d), info(i) {}
@@ -177,7 +179,13 @@ struct Emitter {
       } else if (n == "arith.maximumf" || n == "arith.minimumf" || n == "arith.maxnumf" || n == "arith.minnumf") {
         o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(6) << "("
           << val(op.operands[0]) << ", " << val(op.operands[1]) << ");\n";
-      } else if (n == "math.sqrt" || n == "math.absf") {
+      } else if (n == "math.powf") {
+        saw_elementary = true;
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::powf(" << val(op.operands[0]) << ", "
+          << val(op.operands[1]) << ");\n";
+      } else if (n == "math.sqrt" || n == "math.absf" || n == "math.exp" || n == "math.log" || n == "math.sin" || n == "math.cos" ||
+                 n == "math.tanh") {
+        if (n != "math.sqrt" && n != "math.absf") saw_elementary = true;
         o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(5) << "("
           << val(op.operands[0]) << ");\n";
       } else if (n == "arith.cmpf") {
@@ -311,7 +319,9 @@ struct Emitter {
     o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
     o << "struct Body_" << tag << " {\n";
     o << "  template <class A>\n  __device__ __forceinline__ " << ctype(res.elem) << " operator()(const A& a) const {\n";
+    saw_elementary = false;
     if (!emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr)) return false;
+    fp.exact = !saw_elementary;
     o << "  }\n};\n";
     o << "using FP_" << tag << " = neptune_hip::Footprint<" << fp.halo_input << ", " << R[0] << ", " << R[1] << ", " << R[2] << ", "
       << ((fp.box && fp.march_ok) ? "true" : "false") << ", " << (fp.march_ok ? "true" : "false");
@@ -488,6 +498,7 @@ struct Emitter {
             ai.box = fp.box;
             ai.halo_input = fp.halo_inputs > 0 ? std::max(fp.halo_input, 0) : -1;  // report: star/box also when the direct kernel runs it
             ai.fused_reduce = true;
+            ai.exact = fp.exact;
             info.applies.push_back(ai);
             continue;
           }
@@ -514,6 +525,7 @@ struct Emitter {
         ai.elem = res.elem;
         ai.halo0 = halo0_of(fp);
         ai.geom_symbol = tag + "__geom";
+        ai.exact = fp.exact;
         // Geometry-level entry of this apply's body: what neptune_hip_apply_builtin is for the library's own
         // bodies (caller-supplied boxes, bounds, region, stream and launch configuration; no allocation,
         // no synchronisation).  The slab decomposition drives user stencils through it.

@@ -16,6 +16,7 @@ struct ApplyInfo {
   std::string elem;           // element type of the apply
   int halo0 = 0;              // reach along dim 0 (what a slab decomposition must hold as ghost planes)
   std::string geom_symbol;    // exported geometry-level entry (empty: none)
+  bool exact = true;          // false: the body uses elementary functions (exp, log, ...): a few ulp, not bit-exact
 };
 struct SigType {
   std::string kind, elem;  // kind: memref | temp | field

@@ -50,6 +50,10 @@ from typing import Dict, List, Optional, Sequence, Tuple, Union
 import numpy as np
 
 
+_ELEMENTARY = {"math.exp": np.exp, "math.log": np.log, "math.sin": np.sin, "math.cos": np.cos, "math.tanh": np.tanh,
+               "math.powf": np.power}
+
+
 class OracleError(Exception):
     pass
 
@@ -977,6 +981,10 @@ class Module:
                     env[op.results[0]] = np.sqrt(self._value(env, op.operands[0], pts))
             elif n == "math.absf":
                 env[op.results[0]] = np.abs(self._value(env, op.operands[0], pts))
+            elif n in _ELEMENTARY:
+                # not exactly specified (libm in the reference's lowering): parity for bodies using these is to a few ulp
+                with np.errstate(all="ignore"):
+                    env[op.results[0]] = _ELEMENTARY[n](*[self._value(env, o, pts) for o in op.operands])
             elif n in _BINI:
                 a, b = (self._value(env, o, pts) for o in op.operands)
                 env[op.results[0]] = _BINI[n](a, b)

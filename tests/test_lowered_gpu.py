@@ -260,6 +260,36 @@ def test_python_dsl_dot_product_and_time_step_on_the_device(env):
     assert bits_equal(out.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("elem", ["f64", "f32"])
+def test_elementary_functions_within_a_few_ulp(env, elem):
+    """bodies with math.exp / log / sin / cos / tanh / powf: device math library vs numpy (the oracle), stated tolerance
+    8 ulp of the result's magnitude scale on every cell; march and direct kernels agree with each other bit for bit
+    (same device functions), copy-through rim exact"""
+    lowering, torch = env
+    from test_lowering import ELEMENTARY
+    n0, n1 = 20, 384
+    text = ELEMENTARY.format(elem=elem, n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1)
+    dt = np.float64 if elem == "f64" else np.float32
+    mod = lowering.compile_module(text)
+    assert mod.report["applies"][0]["exact"] is False
+    u = helpers.hash_field((n0, n1), dt, seed=12)
+    want = oracle.Module.parse(text).call("react", u)
+    d_u = torch.from_numpy(u).cuda()
+    got = mod.call("react", d_u).cpu().numpy()
+    eps = float(np.finfo(dt).eps)
+    scale = np.maximum(np.abs(want), 1.0)            # terms of magnitude <= ~3 are added: absolute errors of a few eps
+    assert np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= 8 * eps * scale), \
+        float(np.max(np.abs(got.astype(np.float64) - want) / (eps * scale)))
+    assert bits_equal(got[0], u[0]) and bits_equal(got[:, -1], u[:, -1])
+    os_env = __import__("os").environ
+    os_env["NEPTUNE_HIP_KERNEL"] = "direct"
+    try:
+        got_direct = mod.call("react", d_u).cpu().numpy()
+    finally:
+        os_env.pop("NEPTUNE_HIP_KERNEL", None)
+    assert bits_equal(got, got_direct)
+
+
 def test_c_caller_in_the_style_of_the_petsc_matmult_thunk(env, tmp_path):
     """a plain C program looks the lowered operator up with dlsym(RTLD_DEFAULT), calls it with a host
     array and free()s the result -- the three things LinSolverCtx::MatMultThunk does

@@ -278,3 +278,70 @@ def test_front_end_survives_mutated_inputs():
     truncated = "module {\n  func.func @f(%a: memref<?xf64>) -> memref<?xf64> attributes {"
     with pytest.raises(lowering.LoweringError, match="unexpected end of input"):
         lowering.verify(truncated)
+
+
+ELEMENTARY = '''
+#l = #neptune_ir.location<"cell">
+!t = !neptune_ir.temp<element = {elem}, bounds = #neptune_ir.bounds<lb = [0, 0], ub = [{n0}, {n1}]>, location = #l>
+module {{
+  // Arrhenius-type reaction term on top of a 5-point diffusion: elementary functions in an apply body
+  neptune_ir.nonlinear_opdef @react : (!t) -> !t {{
+  ^bb0(%u: !t):
+    %r = neptune_ir.apply(%u) attributes {{bounds = #neptune_ir.bounds<lb = [1, 1], ub = [{m0}, {m1}]>}} : (!t) -> !t {{
+      ^bb0(%i: index, %j: index, %a: !t):
+        %c = neptune_ir.access %a[0, 0] : !t -> {elem}
+        %n = neptune_ir.access %a[-1, 0] : !t -> {elem}
+        %s = neptune_ir.access %a[1, 0] : !t -> {elem}
+        %w = neptune_ir.access %a[0, -1] : !t -> {elem}
+        %e = neptune_ir.access %a[0, 1] : !t -> {elem}
+        %half = arith.constant 0.5 : {elem}
+        %two = arith.constant 2.0 : {elem}
+        %ns = arith.addf %n, %s : {elem}
+        %we = arith.addf %w, %e : {elem}
+        %nb = arith.addf %ns, %we : {elem}
+        %ab = math.absf %c : {elem}
+        %den = arith.addf %ab, %half : {elem}
+        %inv = arith.divf %half, %den : {elem}
+        %neg = arith.negf %inv : {elem}
+        %arr = math.exp %neg : {elem}
+        %sn = math.sin %nb : {elem}
+        %cs = math.cos %c : {elem}
+        %th = math.tanh %nb : {elem}
+        %lg = math.log %den : {elem}
+        %pw = math.powf %den, %two : {elem}
+        %t0 = arith.mulf %arr, %sn : {elem}
+        %t1 = arith.addf %t0, %cs : {elem}
+        %t2 = arith.mulf %th, %lg : {elem}
+        %t3 = arith.addf %t1, %t2 : {elem}
+        %t4 = arith.addf %t3, %pw : {elem}
+        neptune_ir.yield %t4 : {elem}
+    }}
+    neptune_ir.return %r : !t
+  }}
+}}
+'''
+
+
+def test_elementary_functions_lower_and_are_flagged_inexact():
+    """math.exp / log / sin / cos / tanh / powf: not exactly specified (libm in the reference's lowering, the device math library
+    here), so such bodies are lowered but reported as "exact": false; everything else stays "exact": true"""
+    text = ELEMENTARY.format(elem="f64", n0=8, n1=128, m0=7, m1=127)
+    lowering.verify(text)
+    src, report = lowering.to_hip(text)
+    for fn in ("exp", "log", "sin", "cos", "tanh"):
+        assert f"neptune_hip::ops::{fn}(" in src
+    assert "neptune_hip::ops::powf(v_den, v_two)" in src
+    assert report["applies"][0]["exact"] is False and report["applies"][0]["kernel"] == "march"
+    _, rep7 = lowering.to_hip((FIXTURE_DIR / "apply-3d-7pt.mlir").read_text())
+    assert rep7["applies"][0]["exact"] is True
+    import numpy as np
+    from helpers import oracle
+    u = helpers.hash_field((8, 128), np.float64, seed=1)
+    got = oracle.Module.parse(text).call("react", u)
+    i, j = 3, 17
+    nb = (u[i - 1, j] + u[i + 1, j]) + (u[i, j - 1] + u[i, j + 1])
+    den = abs(u[i, j]) + 0.5
+    want = ((np.exp(-(0.5 / den)) * np.sin(nb) + np.cos(u[i, j])) + np.tanh(nb) * np.log(den)) + np.power(den, 2.0)
+    assert got[i, j] == want and got[0, 5] == u[0, 5]
+    with pytest.raises(lowering.LoweringError, match="unsupported operation 'math.erf'"):
+        lowering.verify(text.replace("math.tanh %nb", "math.erf %nb"))
