@@ -75,6 +75,11 @@ def gen_apply(rng, name, rank, elem, shape, origin):
         cnt += 1
         L.append(f"%v{cnt} = arith.divf {acc}, {c} : {elem}")
         acc = f"%v{cnt}"
+    if rng.random() < 0.3:                      # sqrt(|x|): IEEE-exact on both sides, unlike exp/log/...
+        cnt += 1
+        L.append(f"%g{cnt} = math.absf {acc} : {elem}")
+        L.append(f"%v{cnt} = math.sqrt %g{cnt} : {elem}")
+        acc = f"%v{cnt}"
     if rng.random() < 0.5:                      # select on a float compare
         z = const()
         cnt += 1
