@@ -39,6 +39,14 @@ __host__ __device__ __forceinline__ float sqrt(float x) { return ::sqrtf(x); }
 __host__ __device__ __forceinline__ double absf(double x) { return ::fabs(x); }
 __host__ __device__ __forceinline__ float absf(float x) { return ::fabsf(x); }
 
+// math.floor / ceil / copysign: exact
+__host__ __device__ __forceinline__ double floor(double x) { return ::floor(x); }
+__host__ __device__ __forceinline__ float floor(float x) { return ::floorf(x); }
+__host__ __device__ __forceinline__ double ceil(double x) { return ::ceil(x); }
+__host__ __device__ __forceinline__ float ceil(float x) { return ::ceilf(x); }
+__host__ __device__ __forceinline__ double copysign(double a, double b) { return ::copysign(a, b); }
+__host__ __device__ __forceinline__ float copysign(float a, float b) { return ::copysignf(a, b); }
+
 // Elementary functions (math.exp / log / sin / cos / tanh / powf).  Unlike everything above these are NOT exactly
 // specified: the reference lowers them to libm calls (math-to-llvm -> intrinsics -> libm on the CPU), this backend
 // to the device math library; both are accurate to about an ulp, not correctly rounded, so results agree to a few

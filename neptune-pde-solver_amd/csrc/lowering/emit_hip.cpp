@@ -179,13 +179,16 @@ struct Emitter {
       } else if (n == "arith.maximumf" || n == "arith.minimumf" || n == "arith.maxnumf" || n == "arith.minnumf") {
         o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(6) << "("
           << val(op.operands[0]) << ", " << val(op.operands[1]) << ");\n";
+      } else if (n == "math.copysign") {
+        o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::copysign(" << val(op.operands[0])
+          << ", " << val(op.operands[1]) << ");\n";
       } else if (n == "math.powf") {
         saw_elementary = true;
         o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::powf(" << val(op.operands[0]) << ", "
           << val(op.operands[1]) << ");\n";
-      } else if (n == "math.sqrt" || n == "math.absf" || n == "math.exp" || n == "math.log" || n == "math.sin" || n == "math.cos" ||
+      } else if (n == "math.sqrt" || n == "math.absf" || n == "math.floor" || n == "math.ceil" || n == "math.exp" || n == "math.log" || n == "math.sin" || n == "math.cos" ||
                  n == "math.tanh") {
-        if (n != "math.sqrt" && n != "math.absf") saw_elementary = true;
+        if (n != "math.sqrt" && n != "math.absf" && n != "math.floor" && n != "math.ceil") saw_elementary = true;
         o << ind << "const " << ctype(op.types[0].elem) << " " << res() << " = neptune_hip::ops::" << n.substr(5) << "("
           << val(op.operands[0]) << ");\n";
       } else if (n == "arith.cmpf") {

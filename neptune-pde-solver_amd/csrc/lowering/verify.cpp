@@ -41,11 +41,12 @@ struct Verifier {
     auto need = [&](size_t k) { if (ots.size() != k) { diag.fail(op.line, "'" + n + "' expects " + std::to_string(k) + " operands"); return false; } return true; };
     const Type decl = op.types.empty() ? Type{} : op.types[0];
     static const std::set<std::string> binf = {"arith.addf", "arith.subf", "arith.mulf", "arith.divf", "arith.maximumf",
-                                               "arith.minimumf", "arith.maxnumf", "arith.minnumf", "math.powf"};
+                                               "arith.minimumf", "arith.maxnumf", "arith.minnumf", "math.powf",
+                                               "math.copysign"};
     static const std::set<std::string> bini = {"arith.addi", "arith.subi", "arith.muli", "arith.andi", "arith.ori", "arith.xori"};
     // math.exp ... math.tanh: elementary functions (libm / device math library: not correctly rounded, a few ulp)
-    static const std::set<std::string> unf = {"arith.negf", "math.sqrt", "math.absf", "math.exp", "math.log",
-                                              "math.sin", "math.cos", "math.tanh"};
+    static const std::set<std::string> unf = {"arith.negf", "math.sqrt", "math.absf", "math.floor", "math.ceil", "math.exp",
+                                              "math.log", "math.sin", "math.cos", "math.tanh"};
     if (binf.count(n)) {
       if (!need(2)) return false;
       if (!is_float(decl) || ots[0] != decl || ots[1] != decl) { diag.fail(op.line, "'" + n + "' operand types must equal its floating-point type"); return false; }

@@ -981,6 +981,11 @@ class Module:
                     env[op.results[0]] = np.sqrt(self._value(env, op.operands[0], pts))
             elif n == "math.absf":
                 env[op.results[0]] = np.abs(self._value(env, op.operands[0], pts))
+            elif n in ("math.floor", "math.ceil"):
+                env[op.results[0]] = (np.floor if n == "math.floor" else np.ceil)(self._value(env, op.operands[0], pts))
+            elif n == "math.copysign":
+                a, b = (self._value(env, o, pts) for o in op.operands)
+                env[op.results[0]] = np.copysign(a, b)
             elif n in _ELEMENTARY:
                 # not exactly specified (libm in the reference's lowering): parity for bodies using these is to a few ulp
                 with np.errstate(all="ignore"):

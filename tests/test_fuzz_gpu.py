@@ -75,6 +75,12 @@ def gen_apply(rng, name, rank, elem, shape, origin):
         cnt += 1
         L.append(f"%v{cnt} = arith.divf {acc}, {c} : {elem}")
         acc = f"%v{cnt}"
+    if rng.random() < 0.25:                     # floor / ceil / copysign: exact
+        cnt += 1
+        f = rng.choice(["math.floor", "math.ceil"])
+        L.append(f"%h{cnt} = {f} {acc} : {elem}")
+        L.append(f"%v{cnt} = math.copysign %h{cnt}, {vals[-1]} : {elem}")
+        acc = binop(f"%v{cnt}", vals[0])
     if rng.random() < 0.3:                      # sqrt(|x|): IEEE-exact on both sides, unlike exp/log/...
         cnt += 1
         L.append(f"%g{cnt} = math.absf {acc} : {elem}")
