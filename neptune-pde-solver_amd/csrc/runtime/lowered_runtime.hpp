@@ -192,8 +192,21 @@ class Scope {
       }
     return nullptr;  // not owned here (an argument or an alias of one)
   }
+  // NEPTUNE_HIP_ASYNC=1: a call whose buffers are all device memory returns without waiting for its kernels;
+  // results are then ordered on the default stream like any other work queued there (torch's default stream on
+  // ROCm), which removes the per-call synchronisation for device-resident time loops.  Temporaries go back to the
+  // block pool while still in flight: safe, because every lowered function and therefore every reuse of a pooled
+  // block is queued on the same stream.  Host buffers and scalar results always synchronise.
+  static bool async_mode() {
+    static const bool on = [] {
+      const char* e = getenv("NEPTUNE_HIP_ASYNC");
+      return e && *e && *e != '0';
+    }();
+    return on;
+  }
   // flush dirty host shadows; called by the exported wrapper before returning
   void finish() {
+    if (async_mode() && !host_mode()) return;
     NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
     for (auto& h : host_args_)
       if (h.dirty) NEPTUNE_HIP_CHECK(hipMemcpy(h.host, h.dev, h.bytes, hipMemcpyDeviceToHost));
@@ -201,7 +214,7 @@ class Scope {
   // result buffer for the caller: host malloc in host mode (caller free()s it), else the device
   // buffer itself (caller neptune_rt_free()s it)
   void* export_result(const Val& v) {
-    NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
+    if (!(async_mode() && !host_mode())) NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
     void* owned = release(v);
     if (host_mode()) {
       size_t bytes = (size_t)v.count * v.esize;

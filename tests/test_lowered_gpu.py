@@ -473,6 +473,43 @@ print("TUNE_OK")
     assert p.returncode == 0 and "TUNE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_async_mode_keeps_results_and_order(env, tmp_path):
+    """NEPTUNE_HIP_ASYNC=1: device-resident calls return without synchronising; chained steps (pooled temporaries reused
+    while earlier kernels may still run), a device result and a scalar result still come out right"""
+    script = tmp_path / "async_mode.py"
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {str(helpers.REPO / 'neptune-pde-solver_amd')!r}); sys.path.insert(0, {str(helpers.REPO / 'tests')!r})
+os.environ["NEPTUNE_CACHE_DIR"] = {str(tmp_path)!r}
+os.environ["NEPTUNE_HIP_ASYNC"] = "1"
+import numpy as np, torch, helpers
+from helpers import oracle, bits_equal
+from neptune_hip import lowering
+text = (helpers.REPO / "tests/mlir_tests/time_stepping/explicit-twostage-3d.mlir").read_text()
+mod = lowering.compile_module(text)
+m = oracle.Module.parse(text)
+u = helpers.hash_field((10, 9, 128), np.float64, seed=11)
+a, b = torch.from_numpy(u).cuda(), torch.zeros((10, 9, 128), dtype=torch.float64, device="cuda")
+ha, hb = u.copy(), np.zeros_like(u)
+for _ in range(40):
+    mod.call("step", b, a)
+    a, b = b, a
+for _ in range(40):
+    m.call("step", hb, ha)
+    ha, hb = hb, ha
+assert bits_equal(a.cpu().numpy(), ha)
+fresh = mod.call("rhs", torch.from_numpy(u).cuda())                    # callee-allocated device result
+assert bits_equal(fresh.cpu().numpy(), m.call("rhs", u))
+out = np.zeros_like(u)
+mod.call("step", out, u)                                               # host buffers: still synchronous
+want = np.zeros_like(u); m.call("step", want, u)
+assert bits_equal(out, want)
+print("ASYNC_OK")
+""")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "ASYNC_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
 def test_temporaries_come_from_the_block_pool(env):
     """an apply result that cannot be written into a destination field (here: in-place update, and the rhs
     temp of the two-stage step) is a pooled device block: cached when the call returns, reused by the next
