@@ -107,6 +107,8 @@ struct MarchVariant {
 //   rank 3, box   : 1  rj4_wj8_wk1_pf2_lds   (512^3 fp32 27-point: 5.6 TB/s)
 //   rank 3, star of radius 2 : 2  rj2_wj8_wk1_pf2_lds_jhl  (5 live planes: fewer rows per lane,
 //                      J halo rows only for the centre plane, so the tile fits the register file)
+//   rank 3, large star fields: 4  rj4_wj16_wk1_pf1_lds (64 rows x one wave span, 16 waves: within 1 % of tile 0 on
+//                      the fastest boxes of the pool and 4-10 % ahead on the others, 512^3-1024^3)
 //   rank 3, small fields     : 3  rj2_wj4_wk1_pf2  (8 rows x one wave span, 4 waves, no LDS: the
 //                      problem is cut into 4-8x more workgroups; 128^3: 10 us instead of 20,
 //                      27-point 256^3: 28 us instead of 46, profiles/r01_size_sweep.txt)
@@ -118,7 +120,8 @@ struct MarchVariant {
   X(0, 4, 4, 2, true, true, 2, false, true, false, false, "rj4_wj4_wk2_pf2_lds")    \
   X(1, 4, 8, 1, true, true, 2, false, true, false, false, "rj4_wj8_wk1_pf2_lds")    \
   X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl") \
-  X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")
+  X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")      \
+  X(4, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
   X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
   X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")             \
@@ -126,29 +129,28 @@ struct MarchVariant {
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(4, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
-  X(5, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(6, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
-  X(7, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
-  X(8, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
-  X(9, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
-  X(10, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
-  X(11, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
-  X(12, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
-  X(13, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
-  X(14, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
-  X(15, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
-  X(16, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
-  X(17, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
-  X(18, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
-  X(19, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
-  X(20, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
-  X(21, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
-  X(22, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
-  X(23, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
-  X(24, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
-  X(25, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds") \
-  X(26, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")
+  X(5, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
+  X(6, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(7, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
+  X(8, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
+  X(9, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
+  X(10, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
+  X(11, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
+  X(12, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
+  X(13, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
+  X(14, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
+  X(15, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
+  X(16, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
+  X(17, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
+  X(18, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
+  X(19, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
+  X(20, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
+  X(21, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
+  X(22, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
+  X(23, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
+  X(24, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
+  X(25, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
+  X(26, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
   X(3, 1, 1, 4, true, true, 2, false, false, false, false, "wk4_pf2")  \
@@ -353,9 +355,12 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
       // third of the lanes idle) take the one-wave-wide tile with twice the rows (measured +10 % at 320^3-640^3)
       if (variant == 0) {
-        const int64_t n2 = g->out_ub[2] - g->out_lb[2], span = kWave * (16 / (int64_t)sizeof(T));
+        const int64_t n1 = g->out_ub[1] - g->out_lb[1], n2 = g->out_ub[2] - g->out_lb[2], span = kWave * (16 / (int64_t)sizeof(T));
         const int64_t wide = (n2 + 2 * span - 1) / (2 * span) * 2 * span, narrow = (n2 + span - 1) / span * span;
         if (wide * 20 > narrow * 21) variant = 1;
+        // large fields: the 64-row tile, unless its rows-per-tile rounding wastes more than the 16-row tile's
+        const int64_t tall = (n1 + 63) / 64 * 64, low = (n1 + 15) / 16 * 16;
+        if (n1 >= 256 && tall * 100 <= low * 106) variant = 4;
       }
       // small fields: if even 16-plane chunks of the default tile give fewer workgroups than CUs (box stencils:
       // than 4 per CU -- their tile is register-heavy and gains from more, smaller workgroups up to ~400^3),
