@@ -196,12 +196,8 @@ class ShardedApply:
             import ctypes as C
             lib = self._apply._capi.load()
             mk = lambda region: (self._apply.geom_for(fins, fout, self.bounds, region), self._apply._in_array(fins))
-            hops = []
-            if self.slab.world > 1:
-                for f in fins:
-                    hops += halo_ops(self.slab, f.tensor, self.group)
             rec = {
-                "halo_ops": hops,
+                "halo_ops": None,      # built at the first exchange (needs the process group; region-only users never exchange)
                 "tensors": [f.tensor for f in fins],
                 "whole": mk(self._own_region()),
                 "interior": mk(self.interior) if self.interior is not None else None,
@@ -233,6 +229,8 @@ class ShardedApply:
         self.ready.record(self.compute)
         with torch.cuda.stream(self.comm):
             self.comm.wait_event(self.ready)
+            if rec["halo_ops"] is None:
+                rec["halo_ops"] = [op for t in rec["tensors"] for op in halo_ops(slab, t, self.group)]
             works = exchange_halos(slab, rec["tensors"][0], self.group, rec["halo_ops"])
             for w in works:
                 w.wait()              # stream-ordered: the comm stream waits for RCCL, the host does not

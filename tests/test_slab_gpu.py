@@ -98,3 +98,21 @@ print("NOT_REACHED")
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert "WHOLE_OK" in p.stdout and "NOT_REACHED" not in p.stdout
     assert p.returncode != 0 and "slab mode: neptune_ir.apply reads neighbouring planes" in p.stderr
+
+
+def test_bench_diagnostic_modes(built_libs):
+    """bench.py's single-process diagnostics keep working: --emulate-rank (the launches one rank of W would issue, no
+    exchange) and a small workload end to end; both print exactly one JSON line with the contract's keys"""
+    import json
+    bench = str(HERE.parent / "bench.py")
+    for extra in (["--emulate-rank", "1/4", "--workload", "3d7_512"], ["--workload", "2d5_1024"]):
+        p = subprocess.run([sys.executable, bench, "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert key in d, key
+        assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.2
