@@ -47,3 +47,16 @@ def test_matrix_free_cg_on_device_matches_the_oracle_driven_solve(built_libs, tm
     m.call("matmult", resid, x)
     assert np.abs(resid - b).max() <= 1e-8 * np.abs(b).max()
     assert np.all(x[0] == 0) and np.all(x[:, :, -1] == 0)          # rim untouched: A is the identity there, b = 0
+
+
+def test_examples_run(built_libs, tmp_path):
+    """the two example programs end to end at small sizes (DSL -> jit -> lowered calls, hipGraph step loop, CG)"""
+    import os
+    import subprocess
+    env = dict(os.environ, NEPTUNE_CACHE_DIR=str(tmp_path))
+    heat = subprocess.run([sys.executable, str(helpers.REPO / "examples/heat_step.py"), "256", "200"], env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert heat.returncode == 0 and "results agree: True" in heat.stdout, heat.stdout[-1500:] + heat.stderr[-3000:]
+    cg = subprocess.run([sys.executable, str(helpers.REPO / "examples/cg_matrix_free.py"), "64"], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert cg.returncode == 0 and "CG:" in cg.stdout and "('dot', 'reduce')" in cg.stdout, cg.stdout[-1500:] + cg.stderr[-3000:]
