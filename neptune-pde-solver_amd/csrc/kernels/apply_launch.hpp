@@ -204,7 +204,8 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   constexpr int WJ = TL::WJ, WK = TL::WK, RJ = TL::RJ;
   const int64_t tileK = (int64_t)WK * kWave * VK, tileJ = (int64_t)WJ * RJ;
   P.Kl = P.N2 / VK * VK - VK;
-  P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl;
+  // a K radius beyond one vector reads two lanes to the right: leave one more vector of ragged rows to the tail
+  P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl - (FP::R2 > VK ? VK : 0);
   P.nK = (uint32_t)((P.Ks + tileK - 1) / tileK);
   P.nJ = (uint32_t)((P.rJ1 - P.rJ0 + tileJ - 1) / tileJ);
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
@@ -289,7 +290,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
   const int64_t nK = g->out_ub[RANK - 1] - g->out_lb[RANK - 1];
   // ragged rows (nK % VK != 0): the kernel stores all whole vectors but the last, the rest of each row
   // goes to a direct-kernel launch (launch_apply below)
-  const int64_t nK_march = (nK % VK == 0) ? nK : nK / VK * VK - VK;
+  const int64_t nK_march = (nK % VK == 0) ? nK : nK / VK * VK - VK - (FP::R2 > VK ? VK : 0);
   ok = ok && nK_march >= VK;
   {
     // in-plane offsets are 32-bit in the march kernel: every extent and one plane's bytes
@@ -350,7 +351,10 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
   constexpr int kNH = popcount_u(FP::HALO_MASK);
   constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
   if (variant < 0 || variant >= march_variant_count(RANK)) {
-    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0) : (RANK == 2 && kNH > 2) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
+    // (2-D stars of radius 3-4 march down the rows like many-input applies: 8192^2 radius 4 measured 4.55 TB/s
+    // against 3.2 on the tile form, whose row halo then is as tall as the tile)
+    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0)
+                        : (RANK == 2 && (kNH > 2 || FP::R0 > 2)) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
       // third of the lanes idle) take the one-wave-wide tile with twice the rows (measured +10 % at 320^3-640^3)
@@ -464,7 +468,7 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     }
     launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
     if (P.N2 % (16 / (int)sizeof(T)) != 0) {
-      // ragged rows: cells [Ks, N2) of every row of the region -- fewer than 2*VK per row -- through the
+      // ragged rows: cells [Ks, N2) of every row of the region -- fewer than 3*VK per row -- through the
       // flat direct kernel (lanes run down the rows: strided, but a fraction of a percent of the field)
       neptune_hip_apply_geom_t tail = *g;
       tail.region_lb[RANK - 1] = P.Ks;

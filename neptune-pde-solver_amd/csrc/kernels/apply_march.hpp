@@ -45,7 +45,8 @@ struct MarchParams {
   // this kernel (a multiple of VK); Kl: the last vector start that may be loaded (N2 rounded down to
   // VK, minus VK).  Aligned rows: Ks = N2, Kl = N2-VK.  Ragged rows (N2 % VK != 0): Ks = Kl, i.e. the
   // lane at Ks loads real cells [Ks,Ks+VK) only to serve as its left neighbour's K halo, and the cells
-  // [Ks,N2) of every row -- fewer than 2*VK -- are left to a direct-kernel launch by the caller.
+  // [Ks,N2) of every row -- fewer than 2*VK -- are left to a direct-kernel launch by the caller.  A K
+  // radius beyond one vector (R2 > VK) reads two lanes to the right: Ks = Kl - VK, so that both are real.
   // Rows then start at any multiple of sizeof(T): loads and stores are unaligned 16-byte accesses.
   int32_t Ks, Kl;
   int32_t plb[3], pub[3];  // apply.bounds in result-physical coordinates (lb - out_lb)
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   constexpr int RJ = TL::RJ, WJ = TL::WJ, WK = TL::WK, PF = TL::PF;
   constexpr bool DPP = TL::DPP, NT = TL::NT, NTL = TL::NTL;
   static_assert(PF >= 1, "prefetch distance");
+  static_assert(FP::R2 <= 2 * (16 / (int)sizeof(T)), "K neighbours come from at most two lanes away");
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
   constexpr bool JK = RANK == 2 && TL::JK2;
@@ -219,7 +221,6 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   constexpr bool JH_LATE = TL::JHL && !BOX && R1 > 0;
   constexpr int PJ = JH_LATE ? R0 : NP - 1;  // plane whose J halo rows are filled at a step
   constexpr int NJH = R1 > 0 ? 2 * R1 : 1;
-  static_assert(R2 <= VK, "K radius larger than one lane's vector is not supported");
   static_assert(HAS_HALO || (R0 == 0 && R1 == 0 && R2 == 0), "pointwise footprint must have zero radii");
   // J-halo exchange through LDS needs a vertical neighbour in the workgroup and a J radius that
   // one neighbour can serve
@@ -494,8 +495,24 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
             if constexpr (BOX || (s >= R1 && s < R1 + RJ)) {
               static_for<R2>([&](auto xc) {
                 constexpr int x = xc;
-                lft[h][ph][s][x] = from_prev<DPP>(ring[h][p][s][VK - R2 + x], khl[h][ph][s][x], lane);
-                rgt[h][ph][s][x] = from_next<DPP>(ring[h][p][s][x], khr[h][ph][s][x], lane);
+                // lft[x] = cell k0 - dl, rgt[x] = cell k0 + VK - 1 + dr.  Up to VK cells away the value sits in the
+                // adjacent lane: one wave shift, the wave's edge lane takes the scalar halo cell.  From VK+1 to 2*VK
+                // cells away (radius 3-4 in fp64) it sits two lanes away: two shifts -- the first one feeds the
+                // outermost lane the nearer halo cell, which the second shift hands to its neighbour while the
+                // outermost lane itself receives the farther halo cell.
+                constexpr int dl = R2 - x, dr = x + 1;
+                if constexpr (dl <= VK) {
+                  lft[h][ph][s][x] = from_prev<DPP>(ring[h][p][s][VK - dl], khl[h][ph][s][x], lane);
+                } else {
+                  const T one = from_prev<DPP>(ring[h][p][s][2 * VK - dl], khl[h][ph][s][R2 - (dl - VK)], lane);
+                  lft[h][ph][s][x] = from_prev<DPP>(one, khl[h][ph][s][x], lane);
+                }
+                if constexpr (dr <= VK) {
+                  rgt[h][ph][s][x] = from_next<DPP>(ring[h][p][s][dr - 1], khr[h][ph][s][x], lane);
+                } else {
+                  const T one = from_next<DPP>(ring[h][p][s][dr - 1 - VK], khr[h][ph][s][dr - 1 - VK], lane);
+                  rgt[h][ph][s][x] = from_next<DPP>(one, khr[h][ph][s][x], lane);
+                }
               });
             }
           });

@@ -1,6 +1,6 @@
 """Seeded random applies through the whole route (NeptuneIR text -> lowering -> hipcc -> module ABI -> kernels),
 bit for bit against the oracle: random rank / element type / number of inputs, star and box footprints of radius
-1-2 spread over several inputs, bodies mixing arith/math ops, selects, scf.if on region index arguments with a
+1-2 (1-5 in 1-D / 2-D) spread over several inputs, bodies mixing arith/math ops, selects, scf.if on region index arguments with a
 conditional access, ragged and aligned rows, apply bounds tighter than the halo margin.  Every case runs on the
 automatic kernel choice, on both forms of the direct kernel and -- when the body can march -- on each default
 tile with chunk seams."""
@@ -20,6 +20,8 @@ CONSTS = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 3.0, -0.0625, 1.75, 
 def gen_apply(rng, name, rank, elem, shape, origin):
     nin = int(rng.integers(1, 4))
     radius = int(rng.choice([1, 1, 2]))
+    if rank < 3 and min(shape) >= 11 and rng.random() < 0.3:       # high-order stars (march kernel up to radius 4)
+        radius = int(rng.choice([3, 4, 5]))
     box = radius == 1 and rank > 1 and rng.random() < 0.35
     accesses = []                       # (input, offsets)
     for k in range(nin):
@@ -92,7 +94,7 @@ def gen_apply(rng, name, rank, elem, shape, origin):
         L.append(f"%p{cnt} = arith.cmpf {rng.choice(['olt', 'oge', 'une', 'ogt'])}, {vals[0]}, {z} : {elem}")
         L.append(f"%v{cnt} = arith.select %p{cnt}, {acc}, {vals[-1]} : {elem}")
         acc = f"%v{cnt}"
-    margin = 2 if radius == 2 else 1
+    margin = radius
     if rng.random() < 0.6:                      # scf.if on an index argument, with a conditional access
         d = int(rng.integers(0, rank))
         thr = origin[d] + int(shape[d] // 2)

@@ -99,6 +99,15 @@ CASES = {
     # a CU); the kernel then takes its halo rows from global memory instead (found by tools/soak_fuzz.py, seeds 1038/1044)
     "three_radius2_2d": ((26, 256), "f64", 3, [(k, o) for k in range(3) for o in star(2, 2)], 2, "march"),
     "four_radius2_2d_f32": ((22, 512), "f32", 4, [(k, o) for k in range(4) for o in star(2, 2)[:7]], 2, "march"),
+    # high-order stars in 1-D / 2-D: radius 3-4 (6th / 8th-order operators).  K neighbours beyond one lane vector (fp64: 2 cells)
+    # come through a second wave shift; rows of radius 4 through the LDS exchange of the 4-wave tile
+    "radius4_2d": ((30, 384), "f64", 1, [(0, o) for o in star(2, 4)], 4, "march"),
+    "radius3_2d_ragged": ((25, 261), "f64", 1, [(0, o) for o in star(2, 3)], 3, "march"),
+    "radius4_2d_f32": ((28, 512), "f32", 1, [(0, o) for o in star(2, 4)], 4, "march"),
+    "radius4_1d": ((5000,), "f64", 1, [(0, o) for o in star(1, 4)], 4, "march"),
+    "radius8_1d_f32": ((3000,), "f32", 1, [(0, o) for o in star(1, 8)], 8, "march"),
+    "radius3_pair_2d": ((26, 256), "f64", 2, [(0, o) for o in star(2, 3)] + [(1, o) for o in star(2, 3)[1:]], 3, "direct"),
+    "radius5_2d": ((30, 256), "f64", 1, [(0, o) for o in star(2, 5)], 5, "direct"),
     "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
     "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
     # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
