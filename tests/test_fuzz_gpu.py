@@ -1,6 +1,6 @@
 """Seeded random applies through the whole route (NeptuneIR text -> lowering -> hipcc -> module ABI -> kernels),
 bit for bit against the oracle: random rank / element type / number of inputs, star and box footprints of radius
-1-2 (1-5 in 1-D / 2-D) spread over several inputs, bodies mixing arith/math ops, selects, scf.if on region index arguments with a
+1-2 (1-5 in 1-D / 2-D, 1-4 in 3-D) spread over several inputs, bodies mixing arith/math ops, selects, scf.if on region index arguments with a
 conditional access, ragged and aligned rows, apply bounds tighter than the halo margin.  Every case runs on the
 automatic kernel choice, on both forms of the direct kernel and -- when the body can march -- on each default
 tile with chunk seams."""
@@ -22,6 +22,8 @@ def gen_apply(rng, name, rank, elem, shape, origin):
     radius = int(rng.choice([1, 1, 2]))
     if rank < 3 and min(shape) >= 11 and rng.random() < 0.3:       # high-order stars (march kernel up to radius 4)
         radius = int(rng.choice([3, 4, 5]))
+    elif rank == 3 and min(shape) >= 9 and rng.random() < 0.25:    # 3-D: up to radius 3
+        radius = int(rng.choice([3, 3, 4]))
     box = radius == 1 and rank > 1 and rng.random() < 0.35
     accesses = []                       # (input, offsets)
     for k in range(nin):

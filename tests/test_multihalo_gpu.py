@@ -111,6 +111,9 @@ CASES = {
     "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
     "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
     # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
+    "radius3_3d": ((14, 18, 256), "f64", 1, [(0, o) for o in star(3, 3)], 3, "march"),
+    "radius3_3d_f32_ragged": ((13, 17, 261), "f32", 1, [(0, o) for o in star(3, 3)], 3, "march"),
+    "radius4_3d": ((12, 12, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "direct"),
     "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "direct"),
 }
 
