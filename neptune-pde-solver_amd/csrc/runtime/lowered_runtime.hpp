@@ -94,10 +94,18 @@ class Scope {
     if (r.ub[0] < r.lb[0]) r.ub[0] = r.lb[0];
     return r;
   }
+  // loop bounds with lb > ub along a dimension: the reference's scf.for nest (DataflowLowering.cpp:289-310 for
+  // apply, :604-611 for reduce) makes zero trips, i.e. the box is empty
+  static Box zero_trip(const Box& b) {
+    Box r = b;
+    for (int d = 0; d < r.rank; ++d)
+      if (r.ub[d] < r.lb[d]) r.ub[d] = r.lb[d];
+    return r;
+  }
   // a bounds attribute -> the part this rank computes: its owned planes, or (with_ghosts) all the
   // planes it holds
   Box owned_bounds(const Box& b, bool with_ghosts = false) const {
-    Box r = b;
+    Box r = zero_trip(b);
     if (!slab_on_) return r;
     const int64_t lo = slab_[0] - (with_ghosts ? slab_[2] : 0), hi = slab_[1] + (with_ghosts ? slab_[3] : 0);
     if (r.lb[0] < lo) r.lb[0] = lo;
@@ -384,7 +392,7 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
   double r = 0.0;
   Box clipped;
   const Box* bounds = bounds_decl;
-  if (sc.slab()) {
+  if (sc.slab() || bounds_decl) {
     clipped = sc.owned_bounds(bounds_decl ? *bounds_decl : src.box);
     bounds = &clipped;
     if (clipped.count() == 0) return 0.0;

@@ -135,6 +135,13 @@ def main():
     shp, elem, nin, acc, margin, _ = mh.CASES["swe3d_two_stars"]
     swe = mh.module_text((24, 10, 128), elem, nin, acc, [1, 1, 1], [23, 9, 127])
     ok["geom_entry_two_halo_inputs"] = run_geom_entry_case(rank, world, swe, "resid", (24, 10, 128), 1, 2, 2)
+    # high-order stars: three / four ghost planes per side
+    _, elem, nin, acc, _, _ = mh.CASES["radius3_3d"]
+    r3 = mh.module_text((24, 14, 128), elem, nin, acc, [3, 3, 3], [21, 11, 125])
+    ok["geom_entry_19pt_radius3"] = run_geom_entry_case(rank, world, r3, "resid", (24, 14, 128), 3, 1, 2)
+    _, elem, nin, acc, _, _ = mh.CASES["radius4_2d"]
+    r4 = mh.module_text((40, 256), elem, nin, acc, [4, 4], [36, 252])
+    ok["geom_entry_2d_radius4"] = run_geom_entry_case(rank, world, r4, "resid", (40, 256), 4, 1, 2)
     # reduce: every rank sums its owned planes, the partial sums are added
     n0, n1 = 37, 256
     red = lowering.compile_module(SUMSQ.format(n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1))

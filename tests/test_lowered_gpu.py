@@ -562,3 +562,42 @@ def test_smoke_script_in_the_shape_of_the_reference_smoke_apply(tmp_path):
                        env=dict(__import__("os").environ, WORKDIR=str(tmp_path)))
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert "SMOKE_OK" in p.stdout and "x[1]=0.000000" in p.stdout and "x[23]=24.000000" in p.stdout
+
+
+ZERO_TRIP = '''
+#l = #neptune_ir.location<"cell">
+#b = #neptune_ir.bounds<lb = [0, 0], ub = [12, 256]>
+!t = !neptune_ir.temp<element = f64, bounds = #b, location = #l>
+!f = !neptune_ir.field<element = f64, bounds = #b, location = #l>
+module {
+  func.func @entry(%o: memref<?x?xf64>, %a: memref<?x?xf64>) -> f64 {
+    %fa = neptune_ir.wrap %a : memref<?x?xf64> -> !f
+    %fo = neptune_ir.wrap %o : memref<?x?xf64> -> !f
+    %u = neptune_ir.load %fa : !f -> !t
+    %r = neptune_ir.apply(%u) attributes {bounds = #neptune_ir.bounds<lb = [7, 1], ub = [5, 255]>} : (!t) -> !t {
+      ^bb0(%i: index, %j: index, %x: !t):
+        %w = neptune_ir.access %x[-1, 0] : !t -> f64
+        %e = neptune_ir.access %x[1, 0] : !t -> f64
+        %s = arith.addf %w, %e : f64
+        neptune_ir.yield %s : f64
+    }
+    neptune_ir.store %r to %fo : !t to !f
+    %z = neptune_ir.reduce %u in #neptune_ir.bounds<lb = [3, 9], ub = [9, 4]> {kind = "sum"} : !t -> f64
+    func.return %z : f64
+  }
+}
+'''
+
+
+def test_loop_bounds_with_lb_above_ub_make_zero_trips(env):
+    """an apply or reduce whose bounds run backwards along a dimension lowers to scf.for loops that make no
+    trip in the reference (DataflowLowering.cpp:289-310, :604-611): nothing is computed, the sum is 0"""
+    lowering, torch = env
+    mod = lowering.compile_module(ZERO_TRIP)
+    u = helpers.hash_field((12, 256), np.float64, seed=41)
+    want = np.full_like(u, -3.0)
+    want_sum = oracle.Module.parse(ZERO_TRIP).call("entry", want, u)
+    d_out = torch.full(u.shape, -3.0, dtype=torch.float64, device="cuda")
+    got_sum = mod.call("entry", d_out, torch.from_numpy(u).cuda())
+    assert want_sum == 0.0 and got_sum == 0.0
+    assert bits_equal(d_out.cpu().numpy(), want)
