@@ -352,9 +352,10 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
   constexpr bool kWideState = FP::R0 > 1 || FP::R1 > 1 || kNH > 1;
   if (variant < 0 || variant >= march_variant_count(RANK)) {
     // (2-D stars of radius 3-4 march down the rows like many-input applies: 8192^2 radius 4 measured 4.55 TB/s
-    // against 3.2 on the tile form, whose row halo then is as tall as the tile)
+    // against 3.2 on the tile form, whose row halo then is as tall as the tile; likewise the 25-point 5x5 box: 3.3
+    // against 2.4)
     variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0)
-                        : (RANK == 2 && (kNH > 2 || FP::R0 > 2)) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
+                        : (RANK == 2 && (kNH > 2 || FP::R0 > 2 || (FP::BOX && FP::R0 > 1))) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
       // third of the lanes idle) take the one-wave-wide tile with twice the rows (measured +10 % at 320^3-640^3)

@@ -294,11 +294,11 @@ struct Emitter {
     // holds a radius-3 ring in 209 VGPRs without scratch), at most two halo inputs (one beyond radius 1).
     // 1-D / 2-D, where a plane is one row: stars up to radius 4 (8th-order operators; K neighbours beyond one lane
     // vector come through a second wave shift, so the K radius may reach two vectors), up to four halo inputs
-    // (one beyond radius 2: the register rings of two wide inputs leave one wave per SIMD).  Wider footprints use
-    // the direct kernel.
-    const int rmax = fp.box ? 1 : (rank == 3 ? 3 : 4);
+    // (one beyond radius 2: the register rings of two wide inputs leave one wave per SIMD), boxes up to radius 2
+    // (5x5 windows, one halo input).  Wider footprints use the direct kernel.
+    const int rmax = fp.box ? (rank == 3 ? 1 : 2) : (rank == 3 ? 3 : 4);
     const int rbig = std::max(R[0], std::max(R[1], R[2]));
-    const int hmax = rank == 3 ? (rbig > 1 ? 1 : 2) : (rbig > 2 ? 1 : 4);
+    const int hmax = rank == 3 ? (rbig > 1 ? 1 : 2) : ((rbig > 2 || (fp.box && rbig > 1)) ? 1 : 4);
     fp.march_ok = fp.halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= (rank == 3 ? rmax : 2 * vk) && R[2] <= 2 * vk;
     if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }
     return true;

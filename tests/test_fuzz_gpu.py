@@ -24,7 +24,7 @@ def gen_apply(rng, name, rank, elem, shape, origin):
         radius = int(rng.choice([3, 4, 5]))
     elif rank == 3 and min(shape) >= 9 and rng.random() < 0.25:    # 3-D: up to radius 3
         radius = int(rng.choice([3, 3, 4]))
-    box = radius == 1 and rank > 1 and rng.random() < 0.35
+    box = (radius == 1 and rank > 1 and rng.random() < 0.35) or (radius == 2 and rank == 2 and rng.random() < 0.4)
     accesses = []                       # (input, offsets)
     for k in range(nin):
         style = rng.choice(["centre", "halo"]) if k > 0 else "halo"
@@ -34,7 +34,7 @@ def gen_apply(rng, name, rank, elem, shape, origin):
         n_off = int(rng.integers(2, 7))
         for _ in range(n_off):
             if box:
-                off = tuple(int(rng.integers(-1, 2)) for _ in range(rank))
+                off = tuple(int(rng.integers(-radius, radius + 1)) for _ in range(rank))
             else:
                 d = int(rng.integers(0, rank))
                 off = tuple(int(rng.choice([-radius, -1, 1, radius])) if a == d else 0 for a in range(rank))

@@ -111,6 +111,10 @@ CASES = {
     "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
     "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
     # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
+    # 2-D 25-point box (5x5 window): K halos for every ring row, two-row LDS exchange with corners
+    "box25_2d": ((30, 256), "f64", 1, [(0, (a, b)) for a in range(-2, 3) for b in range(-2, 3)], 2, "march"),
+    "box25_2d_f32_ragged": ((29, 515), "f32", 1, [(0, (a, b)) for a in range(-2, 3) for b in range(-2, 3) if (a + b) % 3], 2, "march"),
+    "box25_pair_2d": ((20, 256), "f64", 2, [(k, (a, b)) for k in range(2) for a in (-2, 0, 2) for b in (-2, 1)], 2, "direct"),
     "radius3_3d": ((14, 18, 256), "f64", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius3_3d_f32_ragged": ((13, 17, 261), "f32", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius4_3d": ((12, 12, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "direct"),
