@@ -117,7 +117,8 @@ CASES = {
     "box25_pair_2d": ((20, 256), "f64", 2, [(k, (a, b)) for k in range(2) for a in (-2, 0, 2) for b in (-2, 1)], 2, "direct"),
     "radius3_3d": ((14, 18, 256), "f64", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius3_3d_f32_ragged": ((13, 17, 261), "f32", 1, [(0, o) for o in star(3, 3)], 3, "march"),
-    "radius4_3d": ((12, 12, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "direct"),
+    "radius4_3d": ((12, 14, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "march"),
+    "radius4_3d_f32": ((13, 12, 260), "f32", 1, [(0, o) for o in star(3, 4)], 4, "march"),
     "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "direct"),
 }
 
