@@ -107,6 +107,9 @@ struct MarchVariant {
 //   rank 3, box   : 1  rj4_wj8_wk1_pf2_lds   (512^3 fp32 27-point: 5.6 TB/s)
 //   rank 3, star of radius 2 : 2  rj2_wj8_wk1_pf2_lds_jhl  (5 live planes: fewer rows per lane,
 //                      J halo rows only for the centre plane, so the tile fits the register file)
+//   rank 3, star of radius 4 : 5  rj2_wj8_wk1_pf1_lds_jhl  (9 live planes: one plane in flight instead of two keeps
+//                      the 25-point operator out of scratch: 512^3 fp64 2.7 TB/s against 2.1; at radius 2-3 the deeper
+//                      prefetch of tile 2 wins, 3.6 against 2.8 for the 19-point operator)
 //   rank 3, large star fields: 4  rj4_wj16_wk1_pf1_lds (64 rows x one wave span, 16 waves: within 1 % of tile 0 on
 //                      the fastest boxes of the pool and 4-10 % ahead on the others, 512^3-1024^3)
 //   rank 3, small fields     : 3  rj2_wj4_wk1_pf2  (8 rows x one wave span, 4 waves, no LDS: the
@@ -121,7 +124,8 @@ struct MarchVariant {
   X(1, 4, 8, 1, true, true, 2, false, true, false, false, "rj4_wj8_wk1_pf2_lds")    \
   X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl") \
   X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")      \
-  X(4, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")
+  X(4, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")  \
+  X(5, 2, 8, 1, true, true, 1, false, true, false, true, "rj2_wj8_wk1_pf1_lds_jhl")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
   X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
   X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")             \
@@ -129,28 +133,28 @@ struct MarchVariant {
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(5, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
-  X(6, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(7, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
-  X(8, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
-  X(9, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
-  X(10, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
-  X(11, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
-  X(12, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
-  X(13, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
-  X(14, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
-  X(15, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
-  X(16, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
-  X(17, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
-  X(18, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
-  X(19, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
-  X(20, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
-  X(21, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
-  X(22, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
-  X(23, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
-  X(24, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
-  X(25, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
-  X(26, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds")
+  X(6, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
+  X(7, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(8, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
+  X(9, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
+  X(10, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
+  X(11, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
+  X(12, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
+  X(13, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
+  X(14, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
+  X(15, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
+  X(16, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
+  X(17, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
+  X(18, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
+  X(19, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
+  X(20, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
+  X(21, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
+  X(22, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
+  X(23, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
+  X(24, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
+  X(25, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
+  X(26, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
+  X(27, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
   X(3, 1, 1, 4, true, true, 2, false, false, false, false, "wk4_pf2")  \
@@ -354,7 +358,7 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     // (2-D stars of radius 3-4 march down the rows like many-input applies: 8192^2 radius 4 measured 4.55 TB/s
     // against 3.2 on the tile form, whose row halo then is as tall as the tile; likewise the 25-point 5x5 box: 3.3
     // against 2.4)
-    variant = RANK == 3 ? (kWideState ? 2 : FP::BOX ? 1 : 0)
+    variant = RANK == 3 ? (kWideState ? (FP::R0 > 3 ? 5 : 2) : FP::BOX ? 1 : 0)
                         : (RANK == 2 && (kNH > 2 || FP::R0 > 2 || (FP::BOX && FP::R0 > 1))) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a

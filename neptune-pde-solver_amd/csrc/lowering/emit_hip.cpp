@@ -291,8 +291,8 @@ struct Emitter {
     const int vk = 16 / esize(res.elem);
     // the march kernel keeps 2*R0+1 planes of RJ+2*R1 rows per halo input in registers.  3-D: radius 1 for box
     // stencils, up to 4 for stars (4th/6th/8th-order 13-, 19- and 25-point operators; the 2-row late-J-halo tile
-    // holds a radius-3 ring in 209 VGPRs without scratch, a radius-4 ring with 15 spilled dwords and still about
-    // twice the direct kernel's rate), at most two halo inputs (one beyond radius 1).
+    // holds a radius-3 ring in 209 VGPRs without scratch, a radius-4 ring in 229 with one plane in flight), at most
+    // two halo inputs (one beyond radius 1).
     // 1-D / 2-D, where a plane is one row: stars up to radius 4 (8th-order operators; K neighbours beyond one lane
     // vector come through a second wave shift, so the K radius may reach two vectors), up to four halo inputs
     // (one beyond radius 2: the register rings of two wide inputs leave one wave per SIMD), boxes up to radius 2

@@ -15,7 +15,7 @@ python tools/make_multihalo_mlir.py radius4_3d 512 512 512 > /tmp/r4_3d.mlir
 python tools/make_multihalo_mlir.py radius4_3d_f32 512 512 512 > /tmp/r4_3d_f32.mlir
 : > gpurun_out/ho_time.log
 for m in ${CASES:-r4_2d r4_2d_f32 r3_2d_ragged r4_1d r8_1d_f32 r3_3d r3_3d_f32_ragged box25_2d box25_2d_f32_ragged r4_3d r4_3d_f32}; do
-  for v in auto 0 1 2 3 direct; do
+  for v in ${VARIANTS:-auto 0 1 2 3 direct}; do
     unset NEPTUNE_HIP_VARIANT NEPTUNE_HIP_KERNEL
     if [ $v = direct ]; then export NEPTUNE_HIP_KERNEL=direct; elif [ $v != auto ]; then export NEPTUNE_HIP_VARIANT=$v; fi
     echo "== $m variant=$v" >> gpurun_out/ho_time.log
