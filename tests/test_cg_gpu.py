@@ -50,7 +50,8 @@ def test_matrix_free_cg_on_device_matches_the_oracle_driven_solve(built_libs, tm
 
 
 def test_examples_run(built_libs, tmp_path):
-    """the two example programs end to end at small sizes (DSL -> jit -> lowered calls, hipGraph step loop, CG)"""
+    """the example programs end to end at small sizes (DSL -> jit -> lowered calls, hipGraph step loop, CG, the
+    25-point leapfrog wave step)"""
     import os
     import subprocess
     env = dict(os.environ, NEPTUNE_CACHE_DIR=str(tmp_path))
@@ -60,3 +61,7 @@ def test_examples_run(built_libs, tmp_path):
     cg = subprocess.run([sys.executable, str(helpers.REPO / "examples/cg_matrix_free.py"), "64"], env=env,
                         capture_output=True, text=True, timeout=600)
     assert cg.returncode == 0 and "CG:" in cg.stdout and "('dot', 'reduce')" in cg.stdout, cg.stdout[-1500:] + cg.stderr[-3000:]
+    wave = subprocess.run([sys.executable, str(helpers.REPO / "examples/wave_25pt.py"), "64", "20"], env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert wave.returncode == 0 and "stable: True" in wave.stdout and "('step', 'march')" in wave.stdout, \
+        wave.stdout[-1500:] + wave.stderr[-3000:]
