@@ -252,6 +252,36 @@ def test_several_halo_inputs_get_a_mask_and_shared_radii():
     assert "neptune_hip::Footprint<0, 1, 0, 1, false, true, 0xfu>" in src
 
 
+def test_footprint_limits_of_the_march_kernel():
+    """which footprints the emitter hands to the march kernel (emit_hip.cpp analyze_apply): stars up to radius 4, a K
+    radius of at most two 16-byte lane vectors, 3-D boxes of radius 1, 2-D boxes of radius 2, one wide halo input;
+    every test_multihalo_gpu case is listed with the kernel it expects"""
+    import test_multihalo_gpu as mh
+    for name, (shape, elem, nin, accesses, margin, kernel) in mh.CASES.items():
+        rank = len(shape)
+        _, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [margin] * rank, [n - margin for n in shape]))
+        assert rep["applies"][0]["kernel"] == kernel, name
+
+    def kernel_of(shape, elem, accesses, margin):
+        rank = len(shape)
+        src, rep = lowering.to_hip(mh.module_text(shape, elem, 1, accesses, [margin] * rank, [n - margin for n in shape]))
+        return rep["applies"][0]["kernel"], src
+
+    k, src = kernel_of((20, 20, 128), "f32", [(0, o) for o in mh.star(3, 4)], 4)
+    assert k == "march" and "neptune_hip::Footprint<0, 4, 4, 4, false, true>" in src
+    assert kernel_of((24, 24, 128), "f32", [(0, o) for o in mh.star(3, 5)], 5)[0] == "direct"
+    # 1-D: the K radius may reach two lane vectors (8 f32 cells, 4 f64 cells)
+    assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 8)], 8)[0] == "march"
+    assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 9)], 9)[0] == "direct"
+    assert kernel_of((1024,), "f64", [(0, o) for o in mh.star(1, 4)], 4)[0] == "march"
+    assert kernel_of((1024,), "f64", [(0, o) for o in mh.star(1, 5)], 5)[0] == "direct"
+    # boxes: 27 points in 3-D, 5x5 in 2-D
+    box3 = [(0, (a, b, c)) for a in (-2, 0, 2) for b in (-1, 1) for c in (-2, 2)]
+    assert kernel_of((16, 16, 128), "f64", box3, 2)[0] == "direct"
+    box2 = [(0, (a, b)) for a in range(-3, 4) for b in (-3, 3)]
+    assert kernel_of((32, 256), "f64", box2, 3)[0] == "direct"
+
+
 def test_every_apply_gets_a_geometry_level_entry():
     """the module's counterpart of neptune_hip_apply_builtin: explicit geometry, region, stream and launch cfg"""
     src, report = lowering.to_hip((FIXTURE_DIR / "apply-3d-13pt.mlir").read_text())
