@@ -269,7 +269,7 @@ def test_footprint_limits_of_the_march_kernel():
 
     k, src = kernel_of((20, 20, 128), "f32", [(0, o) for o in mh.star(3, 4)], 4)
     assert k == "march" and "neptune_hip::Footprint<0, 4, 4, 4, false, true>" in src
-    assert kernel_of((24, 24, 128), "f32", [(0, o) for o in mh.star(3, 5)], 5)[0] == "direct"
+    assert kernel_of((24, 24, 128), "f32", [(0, o) for o in mh.star(3, 5) if max(map(abs, o)) in (0, 5)], 5)[0] == "direct"
     # 1-D: the K radius may reach two lane vectors (8 f32 cells, 4 f64 cells)
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 8)], 8)[0] == "march"
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 9)], 9)[0] == "direct"
