@@ -70,7 +70,7 @@ def test_slab_geometry_properties():
     from hypothesis import given, settings, strategies as st
 
     @settings(max_examples=300, deadline=None)
-    @given(st.integers(1, 8), st.integers(1, 3), st.integers(-7, 7), st.data())
+    @given(st.integers(1, 8), st.integers(1, 4), st.integers(-7, 7), st.data())
     def check(world, radius, origin, data):
         n0 = data.draw(st.integers(max(world * radius, world), 200))
         box = ([origin, 0], [origin + n0, 6])
