@@ -19,6 +19,9 @@
 //                wave shift (DPP wave_shr/wave_shl, or ds_bpermute); the cells just
 //                outside the wave's span have wave-uniform addresses and are fetched with
 //                scalar loads (s_load through the constant cache), costing SGPRs, not VGPRs.
+//                A K radius beyond one lane vector (high-order stars: R2 up to 2*VK) takes a
+//                second shift of the shifted value; the wave's edge lanes are patched from the
+//                scalar halo cell of the matching distance.
 //   * fusion   : copy-through and the bounds test are folded into the store: cells outside
 //                apply.bounds get input 0's value, cells inside get body(...).  Nothing is
 //                written twice and no intermediate buffer exists.
