@@ -27,7 +27,7 @@ int neptune_lowering_verify(const char *mlir_text, char **diag_out);
  *               halo0 (reach along dim 0: the ghost planes a slab decomposition must hold) and geom_symbol,
  *               the exported geometry-level entry of that apply (neptune_hip_apply_fn, include/neptune_hip.h)
  * Set NEPTUNE_HIP_FULL_VARIANTS=1 in the environment of neptune_lowering_compile to build every march tile
- * into the module instead of the defaults (for NEPTUNE_HIP_TUNE=1).
+ * into the module instead of the defaults (for NEPTUNE_HIP_TUNE=1). */
 int neptune_lowering_to_hip(const char *mlir_text, char **source_out, char **report_out, char **diag_out);
 
 /* Lower and compile to a shared object with hipcc (--offload-arch=gfx950 -ffp-contract=off),

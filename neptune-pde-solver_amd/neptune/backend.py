@@ -38,7 +38,7 @@ class AOTCompiler:
 
     def compile_and_load(self, builder):
         # a cache hit inside compile_module is a plain dlopen of the cached object
-        return lowering.compile_module(builder.dump())
+        return lowering.compile_module(builder.dump(), cache_directory=self.cache_dir)
 
 
 _shared_compiler: Optional[AOTCompiler] = None

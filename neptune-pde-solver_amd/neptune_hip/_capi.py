@@ -126,12 +126,17 @@ SIGNATURES = {
 _lib = None
 
 
+def library_path() -> Path:
+    """where load() looks for libneptune_hip.so"""
+    return Path(os.environ.get("NEPTUNE_HIP_LIB", LIB_PATH))
+
+
 def load() -> C.CDLL:
     """dlopen libneptune_hip.so (built by `make rt` / __graft_entry__.build()).  No fallback."""
     global _lib
     if _lib is not None:
         return _lib
-    path = Path(os.environ.get("NEPTUNE_HIP_LIB", LIB_PATH))
+    path = library_path()
     if not path.exists():
         raise ImportError(
             f"{path} not found: the NeptuneIR HIP backend has no CPU fallback. "

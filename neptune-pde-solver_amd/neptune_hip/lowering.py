@@ -79,18 +79,51 @@ def cache_dir() -> Path:
     return d
 
 
+_build_id = None
+
+
+def build_id() -> str:
+    """identifies everything besides the module text that a compiled module bakes in: the emitter
+    (libneptune_lowering.so), the header-only kernels and runtime it is compiled against, the public ABI header,
+    and the runtime library it links (size + mtime: its ABI -- geometry struct, pool, tile numbering -- moves with
+    every rebuild).  A cached shared object built against any other state is never loaded."""
+    global _build_id
+    if _build_id is None:
+        h = hashlib.sha256()
+        h.update(_load().neptune_lowering_version())
+        csrc = _capi.PKG_ROOT / "csrc"
+        files = sorted((csrc / "kernels").glob("*.hpp")) + sorted((csrc / "runtime").glob("*.hpp"))
+        files += [_capi.HEADER_PATH, LOWERING_LIB]
+        for f in files:
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+        rt = _capi.library_path()
+        if rt.exists():
+            st = rt.stat()
+            h.update(f"{rt.name}:{st.st_size}:{st.st_mtime_ns}".encode())
+        _build_id = h.hexdigest()[:16]
+    return _build_id
+
+
 def module_hash(text: str) -> str:
-    """cache key: the module text (reference contract, backend.py:26-41: sha256(IR)[:16]); a build with every march
-    tile compiled in (NEPTUNE_HIP_FULL_VARIANTS=1) is a different artefact of the same text"""
+    """cache key: sha256 over the module text (reference contract, backend.py:26-41: sha256(IR)[:16]) AND this
+    build's id -- the reference's artefact depends on the IR alone, a lowered module also bakes in the kernels it was
+    compiled against.  A build with every march tile compiled in (NEPTUNE_HIP_FULL_VARIANTS=1) is a different
+    artefact of the same text."""
     full = os.environ.get("NEPTUNE_HIP_FULL_VARIANTS", "") not in ("", "0")
-    return hashlib.sha256((text + ("\n// all march tiles" if full else "")).encode("utf-8")).hexdigest()[:16]
+    key = text + ("\n// all march tiles" if full else "") + "\n// build " + build_id()
+    return hashlib.sha256(key.encode("utf-8")).hexdigest()[:16]
 
 
-def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: bool = True) -> "LoweredModule":
-    """lower + hipcc (gfx950) + load.  Compiling needs no GPU; loading needs libneptune_hip.so."""
+def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: bool = True,
+                   cache_directory: Optional[os.PathLike] = None) -> "LoweredModule":
+    """lower + hipcc (gfx950) + load.  Compiling needs no GPU; loading needs libneptune_hip.so.  Without an explicit
+    so_path the object lives in `cache_directory` (default: cache_dir()) under its module_hash."""
     lib = _load()
     if so_path is None:
-        so_path = cache_dir() / f"neptune_kernel_{module_hash(text)}.so"
+        directory = Path(cache_directory) if cache_directory else cache_dir()
+        directory.mkdir(parents=True, exist_ok=True)
+        so_path = directory / f"neptune_kernel_{module_hash(text)}.so"
     so_path = Path(so_path)
     rep_path = so_path.with_suffix(".json")
     if not (use_cache and so_path.exists() and rep_path.exists()):
