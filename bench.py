@@ -61,10 +61,14 @@ def parse_args():
                          "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
     ap.add_argument("--fixed-input", action="store_true",
                     help="diagnostic: every step reads field 0 and writes field 1 (no ping-pong)")
-    ap.add_argument("--lowered", action="store_true",
-                    help="run the workload's fixture through the NeptuneIR lowering (neptune-opt emitter + hipcc at start-up) "
-                         "and launch the lowered module's own apply instead of the library's built-in copy of the same body; "
-                         "the library's default tile is used (plan-time tuning covers the built-in bodies only)")
+    ap.add_argument("--builtin", action="store_true",
+                    help="diagnostic: launch the runtime library's built-in copy of the fixture's body instead of the "
+                         "module the lowering produces (default: fixture text -> libneptune_lowering emitter -> hipcc "
+                         "-> the module's own geometry-level apply entry, i.e. the path north_star names)")
+    ap.add_argument("--lowered", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--full-variants", action="store_true",
+                    help="build the lowered module with every march tile of the library (NEPTUNE_HIP_FULL_VARIANTS=1: "
+                         "a longer hipcc run) so that the plan-time tuning can choose among all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-planes", type=int, default=0, help="dim-0 extent of the CPU sample (0 = auto)")
     ap.add_argument("--hbm-traffic-bytes", type=float, default=None,
@@ -164,7 +168,10 @@ def main():
     body_name, gshape, esize, points = WORKLOADS[args.workload]
     body = nh_apply.BODY_BY_NAME[body_name]
     builtin_body = body
+    args.lowered = not args.builtin
     if args.lowered:
+        if args.full_variants:
+            os.environ["NEPTUNE_HIP_FULL_VARIANTS"] = "1"
         sys.path.insert(0, str(REPO / "tools"))
         import make_stencil_mlir
         from neptune_hip import lowering as nh_lowering
@@ -204,7 +211,7 @@ def main():
     # exactly this rank's dominant launch (the interior region of its slab) and keeps the fastest.
     # Every tile computes the same bits; explicit --variant/--chunk/--kernel switch it off.
     autotuned = None
-    if not args.no_autotune and not args.lowered and args.variant < 0 and args.chunk == 0 and args.kernel == "auto":
+    if not args.no_autotune and args.variant < 0 and args.chunk == 0 and args.kernel == "auto":
         probe = slab_mod.ShardedApply(sl, body, gbounds, cfg=None)
         region = probe.interior if (world > 1 or args.emulate_rank) and probe.interior is not None else probe._own_region()
         cfg, tuned_ms = nh_apply.autotune_builtin(body, [bufs[0]], bufs[1], probe.bounds, region=region)

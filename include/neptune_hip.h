@@ -291,6 +291,16 @@ double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t *
 int neptune_hip_autotune_builtin(int body, const neptune_hip_apply_geom_t *g, const void *const *in,
                                  void *out, void *stream, int reps, neptune_hip_launch_cfg_t *best,
                                  double *best_ms);
+/* The same two calls for a lowered apply's geometry-level entry (`fn`, a module's <function>_<k>__geom): the
+ * plan-time tuning a lowered module gets.  num_variants = how many march tiles that module holds
+ * (its <function>_<k>__geom_variants(rank) export; the library's default tiles unless the module was built with
+ * NEPTUNE_HIP_FULL_VARIANTS=1).  A tile that cannot take the geometry is rejected by the entry and skipped. */
+double neptune_hip_time_apply_fn(neptune_hip_apply_fn fn, const neptune_hip_apply_geom_t *g,
+                                 const void *const *in, void *out, void *stream,
+                                 const neptune_hip_launch_cfg_t *cfg, int warmup, int reps);
+int neptune_hip_autotune_fn(neptune_hip_apply_fn fn, int num_variants, const neptune_hip_apply_geom_t *g,
+                            const void *const *in, void *out, void *stream, int reps,
+                            neptune_hip_launch_cfg_t *best, double *best_ms);
 /* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling.
  * mode selects the copy kernel shape (0 .. neptune_hip_copy_mode_count()-1: grid-stride, or
  * 1/2/4/8 loads in flight per lane with optional non-temporal loads/stores). */

@@ -96,6 +96,7 @@ struct MarchVariant {
   bool dpp, nt;
   int PF;
   bool ntl, ldsj, jk, jhl;
+  int KD;
   const char* name;
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
@@ -112,73 +113,85 @@ struct MarchVariant {
 //                      prefetch of tile 2 wins, 3.6 against 2.8 for the 19-point operator)
 //   rank 3, large star fields: 4  rj4_wj16_wk1_pf1_lds (64 rows x one wave span, 16 waves: within 1 % of tile 0 on
 //                      the fastest boxes of the pool and 4-10 % ahead on the others, 512^3-1024^3)
+//   rank 3, largest star fields (two rounds of workgroups and more): 6  rj8_wj4_wk2_pf1_lds_jhl_kd2 (32 rows x two wave
+//                      spans, EIGHT rows per lane, 8 waves = one workgroup per CU at ~200 VGPRs, K halos requested with
+//                      the rows of the same plane: 1024^3 fp64 7-point +5 % over tile 4 on the same box, HBM-side traffic
+//                      1.02x algorithmic against 1.08x -- profiles/r02_headline_search.txt)
 //   rank 3, small fields     : 3  rj2_wj4_wk1_pf2  (8 rows x one wave span, 4 waves, no LDS: the
 //                      problem is cut into 4-8x more workgroups; 128^3: 10 us instead of 20,
 //                      27-point 256^3: 28 us instead of 46, profiles/r01_size_sweep.txt)
 //   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s),
 //                   2  tile_rj4_wj4_wk1      (two halo inputs: 5.6 TB/s against 4.9 on the march form), and
 //                   1  wk4_pf4, the march form (fields of 2 GiB and more, several halo inputs)
-// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)
+// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name)
 #define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(0, 4, 4, 2, true, true, 2, false, true, false, false, "rj4_wj4_wk2_pf2_lds")    \
-  X(1, 4, 8, 1, true, true, 2, false, true, false, false, "rj4_wj8_wk1_pf2_lds")    \
-  X(2, 2, 8, 1, true, true, 2, false, true, false, true, "rj2_wj8_wk1_pf2_lds_jhl") \
-  X(3, 2, 4, 1, true, true, 2, false, false, false, false, "rj2_wj4_wk1_pf2")      \
-  X(4, 4, 16, 1, true, true, 1, false, true, false, false, "rj4_wj16_wk1_pf1_lds")  \
-  X(5, 2, 8, 1, true, true, 1, false, true, false, true, "rj2_wj8_wk1_pf1_lds_jhl")
+  X(0, 4, 4, 2, true, true, 2, false, true, false, false, 1, "rj4_wj4_wk2_pf2_lds")    \
+  X(1, 4, 8, 1, true, true, 2, false, true, false, false, 1, "rj4_wj8_wk1_pf2_lds")    \
+  X(2, 2, 8, 1, true, true, 2, false, true, false, true, 1, "rj2_wj8_wk1_pf2_lds_jhl") \
+  X(3, 2, 4, 1, true, true, 2, false, false, false, false, 1, "rj2_wj4_wk1_pf2")      \
+  X(4, 4, 16, 1, true, true, 1, false, true, false, false, 1, "rj4_wj16_wk1_pf1_lds")  \
+  X(5, 2, 8, 1, true, true, 1, false, true, false, true, 1, "rj2_wj8_wk1_pf1_lds_jhl") \
+  X(6, 8, 4, 2, true, true, 1, false, true, false, true, 2, "rj8_wj4_wk2_pf1_lds_jhl_kd2")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
-  X(0, 4, 8, 1, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk1")        \
-  X(1, 1, 1, 4, true, true, 4, false, false, false, false, "wk4_pf4")             \
-  X(2, 4, 4, 1, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk1")
+  X(0, 4, 8, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj8_wk1")        \
+  X(1, 1, 1, 4, true, true, 4, false, false, false, false, 1, "wk4_pf4")             \
+  X(2, 4, 4, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj4_wk1")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(6, 4, 4, 1, true, true, 2, false, false, false, false, "rj4_wj4_wk1_pf2") \
-  X(7, 4, 4, 1, false, false, 1, false, false, false, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(8, 8, 2, 1, true, true, 1, false, false, false, false, "rj8_wj2_wk1_pf1") \
-  X(9, 4, 4, 1, true, true, 1, false, false, false, false, "rj4_wj4_wk1_pf1") \
-  X(10, 4, 4, 1, true, true, 2, false, true, false, false, "rj4_wj4_wk1_pf2_lds") \
-  X(11, 2, 8, 1, true, true, 4, false, true, false, false, "rj2_wj8_wk1_pf4_lds") \
-  X(12, 8, 4, 1, true, true, 1, false, true, false, false, "rj8_wj4_wk1_pf1_lds") \
-  X(13, 8, 4, 2, true, true, 1, false, true, false, false, "rj8_wj4_wk2_pf1_lds") \
-  X(14, 4, 4, 2, true, true, 3, false, true, false, false, "rj4_wj4_wk2_pf3_lds") \
-  X(15, 4, 2, 4, true, true, 2, false, true, false, false, "rj4_wj2_wk4_pf2_lds") \
-  X(16, 2, 16, 1, true, true, 3, false, true, false, false, "rj2_wj16_wk1_pf3_lds") \
-  X(17, 4, 4, 2, true, true, 2, false, true, false, true, "rj4_wj4_wk2_pf2_lds_jhl") \
-  X(18, 4, 8, 1, true, true, 2, false, true, false, true, "rj4_wj8_wk1_pf2_lds_jhl") \
-  X(19, 8, 4, 2, true, true, 1, false, true, false, true, "rj8_wj4_wk2_pf1_lds_jhl") \
-  X(20, 4, 4, 2, true, true, 3, false, true, false, true, "rj4_wj4_wk2_pf3_lds_jhl") \
-  X(21, 8, 4, 1, true, true, 1, false, true, false, true, "rj8_wj4_wk1_pf1_lds_jhl") \
-  X(22, 8, 4, 2, true, true, 2, false, true, false, true, "rj8_wj4_wk2_pf2_lds_jhl") \
-  X(23, 4, 4, 2, true, true, 4, false, true, false, true, "rj4_wj4_wk2_pf4_lds_jhl") \
-  X(24, 4, 16, 1, true, true, 2, false, true, false, true, "rj4_wj16_wk1_pf2_lds_jhl") \
-  X(25, 2, 16, 1, true, true, 3, false, true, false, true, "rj2_wj16_wk1_pf3_lds_jhl") \
-  X(26, 4, 8, 2, true, true, 2, false, true, false, true, "rj4_wj8_wk2_pf2_lds_jhl") \
-  X(27, 4, 8, 2, true, true, 1, false, true, false, false, "rj4_wj8_wk2_pf1_lds")
+  X(7, 4, 4, 1, true, true, 2, false, false, false, false, 1, "rj4_wj4_wk1_pf2") \
+  X(8, 4, 4, 1, false, false, 1, false, false, false, false, 1, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(9, 8, 2, 1, true, true, 1, false, false, false, false, 1, "rj8_wj2_wk1_pf1") \
+  X(10, 4, 4, 1, true, true, 1, false, false, false, false, 1, "rj4_wj4_wk1_pf1") \
+  X(11, 4, 4, 1, true, true, 2, false, true, false, false, 1, "rj4_wj4_wk1_pf2_lds") \
+  X(12, 2, 8, 1, true, true, 4, false, true, false, false, 1, "rj2_wj8_wk1_pf4_lds") \
+  X(13, 8, 4, 1, true, true, 1, false, true, false, false, 1, "rj8_wj4_wk1_pf1_lds") \
+  X(14, 8, 4, 2, true, true, 1, false, true, false, false, 1, "rj8_wj4_wk2_pf1_lds") \
+  X(15, 4, 4, 2, true, true, 3, false, true, false, false, 1, "rj4_wj4_wk2_pf3_lds") \
+  X(16, 4, 2, 4, true, true, 2, false, true, false, false, 1, "rj4_wj2_wk4_pf2_lds") \
+  X(17, 2, 16, 1, true, true, 3, false, true, false, false, 1, "rj2_wj16_wk1_pf3_lds") \
+  X(18, 4, 4, 2, true, true, 2, false, true, false, true, 1, "rj4_wj4_wk2_pf2_lds_jhl") \
+  X(19, 4, 8, 1, true, true, 2, false, true, false, true, 1, "rj4_wj8_wk1_pf2_lds_jhl") \
+  X(20, 8, 4, 2, true, true, 1, false, true, false, true, 1, "rj8_wj4_wk2_pf1_lds_jhl") \
+  X(21, 4, 4, 2, true, true, 3, false, true, false, true, 1, "rj4_wj4_wk2_pf3_lds_jhl") \
+  X(22, 8, 4, 1, true, true, 1, false, true, false, true, 1, "rj8_wj4_wk1_pf1_lds_jhl") \
+  X(23, 8, 4, 2, true, true, 2, false, true, false, true, 1, "rj8_wj4_wk2_pf2_lds_jhl") \
+  X(24, 4, 4, 2, true, true, 4, false, true, false, true, 1, "rj4_wj4_wk2_pf4_lds_jhl") \
+  X(25, 4, 16, 1, true, true, 2, false, true, false, true, 1, "rj4_wj16_wk1_pf2_lds_jhl") \
+  X(26, 2, 16, 1, true, true, 3, false, true, false, true, 1, "rj2_wj16_wk1_pf3_lds_jhl") \
+  X(27, 4, 8, 2, true, true, 2, false, true, false, true, 1, "rj4_wj8_wk2_pf2_lds_jhl") \
+  X(28, 4, 8, 2, true, true, 1, false, true, false, false, 1, "rj4_wj8_wk2_pf1_lds") \
+  X(29, 4, 4, 2, true, true, 2, false, true, false, false, 2, "rj4_wj4_wk2_pf2_lds_kd2") \
+  X(30, 4, 4, 2, true, true, 2, false, true, false, false, 3, "rj4_wj4_wk2_pf2_lds_kd3") \
+  X(31, 8, 4, 2, true, true, 1, false, true, false, false, 2, "rj8_wj4_wk2_pf1_lds_kd2") \
+  X(32, 8, 8, 1, true, true, 1, false, true, false, false, 2, "rj8_wj8_wk1_pf1_lds_kd2") \
+  X(33, 8, 2, 4, true, true, 1, false, true, false, false, 2, "rj8_wj2_wk4_pf1_lds_kd2") \
+  X(34, 4, 16, 1, true, true, 1, false, true, false, false, 2, "rj4_wj16_wk1_pf1_lds_kd2") \
+  X(35, 4, 16, 1, true, true, 1, true, true, false, false, 1, "rj4_wj16_wk1_pf1_lds_ntl")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
-  X(3, 1, 1, 4, true, true, 2, false, false, false, false, "wk4_pf2")  \
-  X(4, 1, 1, 1, true, true, 4, false, false, false, false, "wk1_pf4")  \
-  X(5, 1, 1, 4, true, true, 8, false, false, false, false, "wk4_pf8")  \
-  X(6, 4, 16, 1, true, true, 1, false, true, true, false, "tile_rj4_wj16_wk1")  \
-  X(7, 8, 8, 1, true, true, 1, false, true, true, false, "tile_rj8_wj8_wk1")    \
-  X(8, 2, 16, 1, true, true, 1, false, true, true, false, "tile_rj2_wj16_wk1")  \
-  X(9, 4, 4, 2, true, true, 1, false, true, true, false, "tile_rj4_wj4_wk2")    \
-  X(10, 4, 8, 2, true, true, 1, false, true, true, false, "tile_rj4_wj8_wk2")   \
-  X(11, 8, 4, 1, true, true, 1, false, true, true, false, "tile_rj8_wj4_wk1")   \
-  X(12, 1, 1, 4, false, false, 1, false, false, false, false, "wk4_pf1_shfl_plainst") \
-  X(13, 4, 8, 1, false, false, 1, false, true, true, false, "tile_rj4_wj8_wk1_shfl_plainst")
+  X(3, 1, 1, 4, true, true, 2, false, false, false, false, 1, "wk4_pf2")  \
+  X(4, 1, 1, 1, true, true, 4, false, false, false, false, 1, "wk1_pf4")  \
+  X(5, 1, 1, 4, true, true, 8, false, false, false, false, 1, "wk4_pf8")  \
+  X(6, 4, 16, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj16_wk1")  \
+  X(7, 8, 8, 1, true, true, 1, false, true, true, false, 1, "tile_rj8_wj8_wk1")    \
+  X(8, 2, 16, 1, true, true, 1, false, true, true, false, 1, "tile_rj2_wj16_wk1")  \
+  X(9, 4, 4, 2, true, true, 1, false, true, true, false, 1, "tile_rj4_wj4_wk2")    \
+  X(10, 4, 8, 2, true, true, 1, false, true, true, false, 1, "tile_rj4_wj8_wk2")   \
+  X(11, 8, 4, 1, true, true, 1, false, true, true, false, 1, "tile_rj8_wj4_wk1")   \
+  X(12, 1, 1, 4, false, false, 1, false, false, false, false, 1, "wk4_pf1_shfl_plainst") \
+  X(13, 4, 8, 1, false, false, 1, false, true, true, false, 1, "tile_rj4_wj8_wk1_shfl_plainst")
 #else
 #define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
 #define NEPTUNE_MARCH2_VARIANTS(X) NEPTUNE_MARCH2_DEFAULT(X)
 #endif
 
-#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name},
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name},
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
 // the tables are indexed by position, the launch switch by the X index: they must agree
-#define NEPTUNE_MV_IDX(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name) idx,
+#define NEPTUNE_MV_IDX(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) idx,
 constexpr int kMarch3Idx[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_IDX)};
 constexpr int kMarch2Idx[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_IDX)};
 #undef NEPTUNE_MV_IDX
@@ -194,11 +207,18 @@ constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
 
 // rank 1: a single tile -- the field is one row, a workgroup is 4 waves side by side, every wave
 // loads its 1 KiB, shifts, stores and retires (the access pattern of the fastest copy kernel)
-constexpr MarchVariant kMarch1[] = {{1, 1, 4, true, true, 1, false, false, false, false, "row_wk4"}};
+constexpr MarchVariant kMarch1[] = {{1, 1, 4, true, true, 1, false, false, false, false, 1, "row_wk4"}};
 inline int march_variant_count(int rank) { return rank == 3 ? kNumMarch3 : (rank == 2 ? kNumMarch2 : (rank == 1 ? 1 : 0)); }
 inline const MarchVariant* march_variant(int rank, int v) {
   if (v < 0 || v >= march_variant_count(rank)) return nullptr;
   return rank == 3 ? &kMarch3[v] : (rank == 2 ? &kMarch2[v] : &kMarch1[v]);
+}
+
+// rows per lane a tile really gets for a footprint: rank-3 footprints with wide register state (boxes, radius 2 and
+// more, several halo inputs) are capped at 4 -- on the 8-row tiles they would only spill
+template <class FP, int RANK>
+constexpr int march_rows(int rj) {
+  return (RANK == 3 && rj > 4 && (FP::BOX || FP::R0 > 1 || FP::R1 > 1 || popcount_u(FP::HALO_MASK) > 1)) ? 4 : rj;
 }
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -260,9 +280,12 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
 template <class Body, class T, int RANK, int NIN, class FP>
 inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, int64_t planes, int chunk,
                          hipStream_t stream) {
-#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, name)                                 \
+  // footprints with wide register state (boxes, radius 2+, several halo inputs) cap the rows per lane at 4: on an
+  // 8-row tile they would only spill (kMarchRowCap)
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name)                             \
   case idx:                                                                                                     \
-    launch_march_variant<Body, T, RANK, NIN, FP, Tile<RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL>>( \
+    launch_march_variant<Body, T, RANK, NIN, FP,                                                                \
+                         Tile<march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD>>( \
         P, body, planes, chunk, stream);                                                                        \
     break;
   if constexpr (RANK == 3) {
@@ -370,6 +393,14 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
         // large fields: the 64-row tile, unless its rows-per-tile rounding wastes more than the 16-row tile's
         const int64_t tall = (n1 + 63) / 64 * 64, low = (n1 + 15) / 16 * 16;
         if (n1 >= 256 && tall * 100 <= low * 106) variant = 4;
+        // the largest fields: the 8-rows-per-lane tile (32 rows x two wave spans), once even 128-plane chunks give every
+        // CU two workgroups and more (1024^3: 1024 of them; 512^3 and the 8-GPU slabs of 1024^3 stay on tile 4, which
+        // is as fast there and splits into more workgroups)
+        if (variant == 4 || variant == 0) {
+          const int64_t p0 = g->region_ub[0] - g->region_lb[0];
+          const int64_t rows32 = (n1 + 31) / 32 * 32;
+          if (rows32 * 100 <= n1 * 104 && ((n1 + 31) / 32) * ((n2 + 2 * span - 1) / (2 * span)) * ((p0 + 127) / 128) >= 512) variant = 6;
+        }
       }
       // small fields: if even 16-plane chunks of the default tile give fewer workgroups than CUs (box stencils:
       // than 4 per CU -- their tile is register-heavy and gains from more, smaller workgroups up to ~400^3),
@@ -389,6 +420,33 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     if (march_variant(2, variant)->jk && field_bytes >= 0x7fffffffLL) variant = 1;
   }
   return variant;
+}
+
+// scratch bytes per lane (register spills) of one rank-3 march tile's kernel for this body; -1 if unknown.  The
+// 8-rows-per-lane tile keeps ~200 VGPRs live for a 7-point body; a body with many more temporaries would spill
+// there and is better off on the 4-row tile.
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int march3_variant_scratch(int variant) {
+  if constexpr (RANK != 3 || !FP::MARCH_OK) {
+    return -1;
+  } else {
+    static std::mutex mu;
+    static std::map<int, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(variant);
+    if (it != cache.end()) return it->second;
+    const void* fn = nullptr;
+#define NEPTUNE_MV_FN(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) \
+  case idx: fn = (const void*)neptune_apply_march<Body, T, RANK, NIN, FP, Tile<march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, false, JHL, KD>>; break;
+    switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_FN) default: break; }
+#undef NEPTUNE_MV_FN
+    int bytes = -1;
+    hipFuncAttributes attr;
+    if (fn && hipFuncGetAttributes(&attr, fn) == hipSuccess) bytes = (int)attr.localSizeBytes;
+    else (void)hipGetLastError();
+    cache[variant] = bytes;
+    return bytes;
+  }
 }
 
 // the direct kernel on g's region: rows form when all coordinates fit 31 bits (see apply_direct.hpp),
@@ -439,6 +497,8 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
     P.out = static_cast<T*>(out);
     int variant = pick_march_variant<T, RANK, FP>(g, cfg);
+    if (RANK == 3 && variant == 6 && !(cfg && cfg->variant == 6) && march3_variant_scratch<Body, T, RANK, NIN, FP>(6) > 0)
+      variant = 4;  // automatic choice only: this body spills on the 8-rows-per-lane tile
     const bool jk = RANK == 2 && march_variant(RANK, variant)->jk;  // rank-2 tile form: (d0,d1) -> (J,K), one plane
     auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
       if (jk) { dst[0] = fill; dst[1] = src[0]; dst[2] = src[1]; }

@@ -187,10 +187,15 @@ struct MarchAcc {
 //         plain copy kernel; the J halo goes through LDS.
 //   JHL   star stencils: obtain the J halo rows when a plane becomes the centre (see JH_LATE in
 //         the kernel) instead of when it arrives
+//   KD    star stencils: how many plane steps ahead of their use the scalar K halos are requested (1 .. 3).  The
+//         cell just outside a wave's span is the edge cell of the K-neighbouring workgroup's row: requested in the
+//         same step as the rows of the same plane (KD = R0 + PF) the two requests for one line fall close together in
+//         time whichever workgroup is ahead, and the later one finds the line in the XCD's L2; requested a step later
+//         (KD = 1) the line has often been evicted again (an XCD streams ~5 MiB per plane step through its 4 MiB L2).
 template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false, bool JK2_ = false,
-          bool JHL_ = false>
+          bool JHL_ = false, int KD_ = 1>
 struct Tile {
-  static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_;
+  static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_, KD = KD_;
   static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_, JHL = JHL_;
 };
 
@@ -215,6 +220,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // live SGPRs for the 7-point stencil.
   constexpr int NPH = BOX ? NP : 1;
   constexpr int HLEAD = BOX ? R0 : 0;  // halos in flight belong to plane i+1+HLEAD
+  // star stencils may request their K halos KD > 1 steps ahead (Tile::KD); a box stencil's ride the ring
+  constexpr int KD = (BOX || !HAS_HALO || R2 == 0 || JK) ? 1 : TL::KD;
+  static_assert(KD >= 1 && KD <= 3, "K halo lead");
+  constexpr int U = (PF % KD == 0) ? PF : (KD % PF == 0 ? KD : PF * KD);  // steps per loop trip: slots stay compile-time
   // J halo rows follow the same split.  A box stencil reads them on every live plane: they are
   // loaded / exchanged when a plane arrives and ride the ring.  A star stencil reads them on the
   // centre plane only: they are obtained when a plane BECOMES the centre (LDS exchange of the
@@ -241,6 +250,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   const int wj = w / WK, wk = w % WK;
 
   // tile decode: K tiles fastest, then J tiles, then chunks of planes
+  // (tried and measured slower: J tiles fastest, chunks fastest, and no XCD remap -- profiles/r02_headline_search.txt)
   const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t kt = v % P.nK;
   const uint32_t t = v / P.nK;
@@ -291,7 +301,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   T khr[NHX][NPH][NR][NS];  // scalar K halos, right
   V nxt[NHX][PF][NR];       // planes in flight (slot ph is consumed by steps i == ph mod PF)
   V njh[NHX][PF][NJH];      // star stencils: J halo rows of the next PF centre planes, in flight
-  T nkhl[NHX][NR][NS], nkhr[NHX][NR][NS];
+  T nkhl[NHX][KD][NR][NS], nkhr[NHX][KD][NR][NS];  // K halos in flight: slot d is consumed by steps i == d mod KD
   V pt[NIN][RJ];            // inputs read at offset 0 only, current plane
   V npt[NIN][RJ];           // ... next plane, in flight
 
@@ -397,7 +407,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
       constexpr int d = dc;
       load_rows(hc, ib + R0 + d, nxt[h][d], std::false_type{});
     });
-    load_khalos(hc, ib + HLEAD, nkhl[h], nkhr[h]);
+    static_for<KD>([&](auto dc) {
+      constexpr int d = dc;
+      load_khalos(hc, ib + HLEAD + d, nkhl[h][d], nkhr[h][d]);
+    });
     static_for<PF>([&](auto dc) {
       constexpr int d = dc;
       load_jhalo(hc, ib + d, njh[h][d]);
@@ -407,8 +420,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
 
   // one plane step; `slot` (compile-time) names the in-flight buffer holding plane i+R0, so no
   // register that a load is still writing is ever moved
-  auto step = [&](const int32_t i, auto slot_c) {
-    constexpr int slot = slot_c;
+  auto step = [&](const int32_t i, auto phase_c) {
+    constexpr int slot = decltype(phase_c)::value % PF, kslot = decltype(phase_c)::value % KD;
     // rotate: ring[p] <- ring[p+1], newest plane <- nxt[slot]
     static_for<NH>([&](auto hc) {
       constexpr int h = hc;
@@ -431,8 +444,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[h][NP - 1][s] = nxt[h][slot][s];
         static_for<NS>([&](auto xc) {
           constexpr int x = xc;
-          khl[h][NPH - 1][s][x] = nkhl[h][s][x];
-          khr[h][NPH - 1][s][x] = nkhr[h][s][x];
+          khl[h][NPH - 1][s][x] = nkhl[h][kslot][s][x];
+          khr[h][NPH - 1][s][x] = nkhr[h][kslot][s][x];
         });
       });
       if constexpr (JH_LATE) {
@@ -480,7 +493,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         load_rows(hc, i + PF + R0, nxt[h][slot], std::false_type{});
         load_jhalo(hc, i + PF, njh[h][slot]);  // the plane that is the centre PF steps from now
       }
-      if (i + 1 < ie) load_khalos(hc, i + 1 + HLEAD, nkhl[h], nkhr[h]);
+      if (i + KD < ie) load_khalos(hc, i + KD + HLEAD, nkhl[h][kslot], nkhr[h][kslot]);
     });
     if (i + 1 < ie) load_point_inputs(i + 1, npt);
 
@@ -551,8 +564,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     });
   };
 
-  for (int32_t i = ib; i < ie; i += PF) {
-    static_for<PF>([&](auto phc) {
+  for (int32_t i = ib; i < ie; i += U) {
+    static_for<U>([&](auto phc) {
       constexpr int ph = phc;
       if (i + ph < ie) step(i + ph, phc);
     });

@@ -544,7 +544,9 @@ struct Emitter {
                      << "  const int rc = neptune_hip::geom_check_radius(g, kTopRadius_" << tag << ");\n"
                      << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
                      << "  return neptune_hip::launch_apply<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
-                     << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n\n";
+                     << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n"
+                     << "// march tiles this module holds for that entry (plan-time tuning: neptune_hip_autotune_fn)\n"
+                     << "extern \"C\" int " << ai.geom_symbol << "_variants(int rank) { return neptune_hip::march_variant_count(rank); }\n\n";
         info.applies.push_back(ai);
       } else if (n == "neptune_ir.time_advance") {
         // explicit Euler step: k = rhs(state); result = state + dt * k, over the whole box.  The

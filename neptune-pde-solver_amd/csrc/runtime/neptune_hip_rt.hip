@@ -95,6 +95,65 @@ size_t body_elem_size(int body) { return body == NEPTUNE_HIP_BODY_LAP3D27_F32 ? 
 
 }  // namespace
 
+namespace {
+// average milliseconds per launch of `launch(cfg)` on `st` (HIP events; blocking); negative = the launch's error code
+template <class L>
+double time_launches(L&& launch, hipStream_t st, const neptune_hip_launch_cfg_t* cfg, int warmup, int reps) {
+  if (reps <= 0) return -1.0;
+  for (int i = 0; i < warmup; ++i) {
+    const int rc = launch(cfg);
+    if (rc != NEPTUNE_HIP_OK) return (double)rc;
+  }
+  hipEvent_t e0, e1;
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+  NEPTUNE_HIP_CHECK(hipEventRecord(e0, st));
+  int rc = NEPTUNE_HIP_OK;
+  for (int i = 0; i < reps && rc == NEPTUNE_HIP_OK; ++i) rc = launch(cfg);
+  NEPTUNE_HIP_CHECK(hipEventRecord(e1, st));
+  NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e0));
+  NEPTUNE_HIP_CHECK(hipEventDestroy(e1));
+  return rc != NEPTUNE_HIP_OK ? (double)rc : (double)ms / reps;
+}
+
+// Plan-time tuning shared by the built-in bodies and lowered applies: the automatic launch first, then every
+// march tile `nv` the code object behind `launch` holds x a few chunk lengths.  All candidates compute the same
+// bits, so the timed launches leave `out` exactly as a normal launch would.
+template <class L>
+int autotune_launches(L&& launch, bool march_planned, int rank, int nv, hipStream_t st, int reps,
+                      neptune_hip_launch_cfg_t* best, double* best_ms) {
+  if (reps <= 0) reps = 5;
+  neptune_hip_launch_cfg_t probe = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
+  *best = probe;
+  double best_t = time_launches(launch, st, &probe, 2, reps);
+  if (best_t < 0) return (int)best_t;
+  if (march_planned) {
+    const int chunks3[] = {0, 32, 64, 128, 256}, chunks2[] = {0};
+    for (int v = 0; v < nv; ++v) {
+      const MarchVariant* mv = march_variant(rank, v);   // indices below the caller's count name the same tiles everywhere
+      if (!mv) break;
+      const bool tile2 = rank == 2 && mv->jk;
+      const int* chunks = (rank == 3 || !tile2) ? chunks3 : chunks2;
+      const int nc = (rank == 3 || !tile2) ? 5 : 1;
+      for (int c = 0; c < nc; ++c) {
+        neptune_hip_launch_cfg_t cfg = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
+        const double t = time_launches(launch, st, &cfg, 1, reps);
+        if (t > 0 && t < best_t) {
+          best_t = t;
+          *best = cfg;
+        }
+      }
+    }
+  }
+  if (best_ms) *best_ms = best_t;
+  return NEPTUNE_HIP_OK;
+}
+}  // namespace
+
+
 extern "C" {
 
 // ---------------------------------------------------------------- runtime
@@ -666,61 +725,38 @@ int64_t neptune_hip_count_mismatch(int dtype, const void* a, const void* b, int6
 double neptune_hip_time_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in,
                                       void* out, void* stream, const neptune_hip_launch_cfg_t* cfg, int warmup,
                                       int reps) {
-  if (reps <= 0) return -1.0;
-  hipStream_t st = as_stream(stream);
-  for (int i = 0; i < warmup; ++i) {
-    int rc = neptune_hip_apply_builtin(body, g, in, out, stream, cfg);
-    if (rc != NEPTUNE_HIP_OK) return (double)rc;
-  }
-  hipEvent_t e0, e1;
-  NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
-  NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
-  NEPTUNE_HIP_CHECK(hipEventRecord(e0, st));
-  for (int i = 0; i < reps; ++i) {
-    int rc = neptune_hip_apply_builtin(body, g, in, out, stream, cfg);
-    if (rc != NEPTUNE_HIP_OK) return (double)rc;
-  }
-  NEPTUNE_HIP_CHECK(hipEventRecord(e1, st));
-  NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
-  float ms = 0.f;
-  NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-  NEPTUNE_HIP_CHECK(hipEventDestroy(e0));
-  NEPTUNE_HIP_CHECK(hipEventDestroy(e1));
-  return (double)ms / reps;
+  return time_launches([&](const neptune_hip_launch_cfg_t* c) { return neptune_hip_apply_builtin(body, g, in, out, stream, c); },
+                       as_stream(stream), cfg, warmup, reps);
+}
+
+double neptune_hip_time_apply_fn(neptune_hip_apply_fn fn, const neptune_hip_apply_geom_t* g, const void* const* in,
+                                 void* out, void* stream, const neptune_hip_launch_cfg_t* cfg, int warmup, int reps) {
+  if (!fn) return (double)NEPTUNE_HIP_EINVAL;
+  return time_launches([&](const neptune_hip_launch_cfg_t* c) { return fn(g, in, out, stream, c); }, as_stream(stream), cfg,
+                       warmup, reps);
 }
 
 int neptune_hip_autotune_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                                  void* stream, int reps, neptune_hip_launch_cfg_t* best, double* best_ms) {
   if (!g || !in || !out || !best) return NEPTUNE_HIP_EINVAL;
-  if (reps <= 0) reps = 5;
   neptune_hip_launch_cfg_t probe = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
   const int planned = neptune_hip_apply_builtin_plan(body, g, in, out, &probe);
   if (planned < 0) return planned;
-  *best = probe;
-  double best_t = neptune_hip_time_apply_builtin(body, g, in, out, stream, &probe, 2, reps);
-  if (best_t < 0) return (int)best_t;
-  if (planned == NEPTUNE_HIP_KERNEL_MARCH) {
-    // every tile the library holds for this rank x a few chunk lengths; all candidates compute the
-    // same bits, so the timed launches leave `out` exactly as a normal launch would
-    const int nv = march_variant_count(g->rank);
-    const int chunks3[] = {0, 32, 64, 128, 256}, chunks2[] = {0};
-    for (int v = 0; v < nv; ++v) {
-      const MarchVariant* mv = march_variant(g->rank, v);
-      const bool tile2 = g->rank == 2 && mv->jk;
-      const int* chunks = (g->rank == 3 || !tile2) ? chunks3 : chunks2;
-      const int nc = (g->rank == 3 || !tile2) ? 5 : 1;
-      for (int c = 0; c < nc; ++c) {
-        neptune_hip_launch_cfg_t cfg = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
-        const double t = neptune_hip_time_apply_builtin(body, g, in, out, stream, &cfg, 1, reps);
-        if (t > 0 && t < best_t) {
-          best_t = t;
-          *best = cfg;
-        }
-      }
-    }
-  }
-  if (best_ms) *best_ms = best_t;
-  return NEPTUNE_HIP_OK;
+  return autotune_launches([&](const neptune_hip_launch_cfg_t* c) { return neptune_hip_apply_builtin(body, g, in, out, stream, c); },
+                           planned == NEPTUNE_HIP_KERNEL_MARCH, g->rank, march_variant_count(g->rank), as_stream(stream), reps,
+                           best, best_ms);
+}
+
+int neptune_hip_autotune_fn(neptune_hip_apply_fn fn, int num_variants, const neptune_hip_apply_geom_t* g,
+                            const void* const* in, void* out, void* stream, int reps, neptune_hip_launch_cfg_t* best,
+                            double* best_ms) {
+  if (!fn || !g || !in || !out || !best) return NEPTUNE_HIP_EINVAL;
+  if (g->rank < 1 || g->rank > kMaxRank) return NEPTUNE_HIP_EINVAL;
+  // whether the automatic launch is a march launch is the module's business; a forced march tile that cannot take
+  // the geometry is rejected by the entry itself (negative return) and simply never becomes the best
+  const int nv = num_variants < 0 ? 0 : (num_variants < march_variant_count(g->rank) ? num_variants : march_variant_count(g->rank));
+  return autotune_launches([&](const neptune_hip_launch_cfg_t* c) { return fn(g, in, out, stream, c); }, nv > 0, g->rank, nv,
+                           as_stream(stream), reps, best, best_ms);
 }
 
 double neptune_hip_time_copy(void* dst, const void* src, size_t bytes, void* stream, int mode, int warmup,

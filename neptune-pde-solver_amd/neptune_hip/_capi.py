@@ -113,6 +113,8 @@ SIGNATURES = {
     "neptune_hip_count_mismatch": (_i64, [_i, _vp, _vp, _i64, _vp]),
     "neptune_hip_time_apply_builtin": (_dbl, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p, _i, _i]),
     "neptune_hip_autotune_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _i, _cfg_p, C.POINTER(C.c_double)]),
+    "neptune_hip_time_apply_fn": (_dbl, [_vp, _geom_p, _vpp, _vp, _vp, _cfg_p, _i, _i]),
+    "neptune_hip_autotune_fn": (_i, [_vp, _i, _geom_p, _vpp, _vp, _vp, _i, _cfg_p, C.POINTER(C.c_double)]),
     "neptune_hip_time_copy": (_dbl, [_vp, _vp, _sz, _vp, _i, _i, _i]),
     "neptune_hip_copy_mode_count": (_i, []),
     "neptune_hip_event_create": (_vp, []),

@@ -84,17 +84,24 @@ def plan_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bou
                        "neptune_hip_apply_builtin_plan")
 
 
-def time_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+def time_builtin(body, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
                  cfg: Optional[_capi.LaunchCfg] = None, warmup: int = 3, reps: int = 20,
                  stream: Optional[int] = None) -> float:
-    """average milliseconds per launch, HIP events on the launch stream (blocking)"""
+    """average milliseconds per launch, HIP events on the launch stream (blocking).  `body`: a built-in body id
+    or a lowered apply's geometry-level entry (LoweredModule.geom_entry)."""
     lib = _capi.load()
     g = geom_for(inputs, out, bounds)
-    ms = lib.neptune_hip_time_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
-                                            current_stream_ptr() if stream is None else stream,
-                                            C.byref(cfg) if cfg is not None else None, warmup, reps)
+    st = current_stream_ptr() if stream is None else stream
+    cfg_p = C.byref(cfg) if cfg is not None else None
+    if hasattr(body, "fn"):
+        what = "neptune_hip_time_apply_fn"
+        ms = lib.neptune_hip_time_apply_fn(C.cast(body.fn, C.c_void_p), C.byref(g), _in_array(inputs), out.ptr, st, cfg_p,
+                                           warmup, reps)
+    else:
+        what = "neptune_hip_time_apply_builtin"
+        ms = lib.neptune_hip_time_apply_builtin(body, C.byref(g), _in_array(inputs), out.ptr, st, cfg_p, warmup, reps)
     if ms < 0:
-        raise _capi.NeptuneHipError(int(ms), "neptune_hip_time_apply_builtin")
+        raise _capi.NeptuneHipError(int(ms), what)
     return ms
 
 
@@ -139,15 +146,22 @@ def reduce_sum(src: DeviceField, bounds: Optional[Box] = None, stream: Optional[
     return out.value
 
 
-def autotune_builtin(body: int, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
+def autotune_builtin(body, inputs: Sequence[DeviceField], out: DeviceField, bounds: Box,
                      region: Optional[Box] = None, reps: int = 5, stream: Optional[int] = None):
-    """plan-time tuning: -> (LaunchCfg of the fastest tile/chunk for this geometry, its ms per launch)"""
+    """plan-time tuning: -> (LaunchCfg of the fastest tile/chunk for this geometry, its ms per launch).  `body`: a
+    built-in body id (every tile of the library is a candidate) or a lowered apply's geometry-level entry (the tiles
+    its module holds: GeomEntry.num_variants)."""
     lib = _capi.load()
     g = geom_for(inputs, out, bounds, region)
     best = _capi.LaunchCfg(0, -1, 0, 0)
     ms = C.c_double(0.0)
-    rc = lib.neptune_hip_autotune_builtin(body, C.byref(g), _in_array(inputs), out.ptr,
-                                          current_stream_ptr() if stream is None else stream, reps, C.byref(best),
-                                          C.byref(ms))
-    _capi.check(rc, "neptune_hip_autotune_builtin")
+    st = current_stream_ptr() if stream is None else stream
+    if hasattr(body, "fn"):
+        rc = lib.neptune_hip_autotune_fn(C.cast(body.fn, C.c_void_p), body.num_variants, C.byref(g), _in_array(inputs),
+                                         out.ptr, st, reps, C.byref(best), C.byref(ms))
+        _capi.check(rc, "neptune_hip_autotune_fn")
+    else:
+        rc = lib.neptune_hip_autotune_builtin(body, C.byref(g), _in_array(inputs), out.ptr, st, reps, C.byref(best),
+                                              C.byref(ms))
+        _capi.check(rc, "neptune_hip_autotune_builtin")
     return best, ms.value

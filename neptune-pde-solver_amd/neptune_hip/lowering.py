@@ -149,6 +149,11 @@ class GeomEntry:
         self.fn.restype = C.c_int
         self.fn.argtypes = [C.POINTER(_capi.ApplyGeom), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                             C.POINTER(_capi.LaunchCfg)]
+        # march tiles the module holds for this entry (the library's defaults unless built with
+        # NEPTUNE_HIP_FULL_VARIANTS=1): the candidates of neptune_hip.apply.autotune_builtin
+        count = getattr(module.lib, self.symbol + "_variants")
+        count.restype, count.argtypes = C.c_int, [C.c_int]
+        self.num_variants = int(count(self.rank))
 
     def __call__(self, geom, in_array, out_ptr, stream, cfg=None) -> int:
         return self.fn(C.byref(geom), in_array, out_ptr, stream, C.byref(cfg) if cfg is not None else None)

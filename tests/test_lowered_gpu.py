@@ -368,7 +368,7 @@ def test_fused_time_step_on_every_kernel_and_tile(env, monkeypatch):
     mod = lowering.compile_module(text)
     assert "step_ta0" in [a["tag"] for a in mod.report["applies"]]
     d_in = torch.from_numpy(u).cuda()
-    for s in [{}, {"NEPTUNE_HIP_KERNEL": "direct"}] + [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "3"} for v in range(6)]:
+    for s in [{}, {"NEPTUNE_HIP_KERNEL": "direct"}] + [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "3"} for v in range(7)]:
         for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
             monkeypatch.delenv(k, raising=False)
         for k, v in s.items():

@@ -164,7 +164,7 @@ def test_several_halo_inputs_match_the_oracle(env, launch_env, name):
     # automatic tile, then every default tile with chunk seams inside the field, then the direct kernel
     settings = [{}]
     if kernel == "march":
-        nvar = {3: 6, 2: 3, 1: 1}[rank]
+        nvar = {3: 7, 2: 3, 1: 1}[rank]
         settings += [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c} for v in range(nvar) for c in ("1", "4")]
         settings += [{"NEPTUNE_HIP_KERNEL": "direct"}]
     for s in settings:

@@ -78,7 +78,7 @@ def main():
             print(f"seed {seed}: skipped (not finite after 3 steps)")
             continue
         for s in [{}, {"NEPTUNE_HIP_KERNEL": "direct"}, {"NEPTUNE_HIP_KERNEL": "direct-flat"}] + \
-                 [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "2"} for v in range({3: 6, 2: 3, 1: 1}[len(shape)])]:
+                 [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "2"} for v in range({3: 7, 2: 3, 1: 1}[len(shape)])]:
             for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
                 os.environ.pop(k, None)
             os.environ.update(s)
