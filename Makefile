@@ -21,15 +21,23 @@ KERNEL_HDRS := $(wildcard $(CSRC)/kernels/*.hpp) $(wildcard $(CSRC)/runtime/*.hp
 .PHONY: all rt lowering oracle clean resources
 all: rt lowering oracle
 
+# two translation units: the kernels + runtime (minutes: every tile x every built-in body) and the host-only slab /
+# RCCL code (seconds)
 rt: $(LIBDIR)/libneptune_hip.so
-$(LIBDIR)/libneptune_hip.so: $(CSRC)/runtime/neptune_hip_rt.hip $(KERNEL_HDRS)
+build/obj/neptune_hip_rt.o: $(CSRC)/runtime/neptune_hip_rt.hip $(KERNEL_HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/obj/slab_rccl.o: $(CSRC)/runtime/slab_rccl.hip $(CSRC)/runtime/slab_rccl.hpp $(CSRC)/kernels/apply_launch.hpp include/neptune_hip.h
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(LIBDIR)/libneptune_hip.so: build/obj/neptune_hip_rt.o build/obj/slab_rccl.o
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared $< -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -ldl -o $@
 
 # per-kernel VGPR/SGPR/occupancy table
 resources: $(CSRC)/runtime/neptune_hip_rt.hip $(KERNEL_HDRS)
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -shared -Rpass-analysis=kernel-resource-usage $< -o build/res.so 2> build/resources.log
+	$(HIPCC) $(HIPFLAGS) -c -Rpass-analysis=kernel-resource-usage $< -o build/res.o 2> build/resources.log
 	python3 tools/kernel_resources.py build/resources.log
 
 LOWERING_SRCS := $(wildcard $(CSRC)/lowering/*.cpp)

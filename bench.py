@@ -59,6 +59,12 @@ def parse_args():
     ap.add_argument("--emulate-rank", default="",
                     help="diagnostic, single process: 'R/W' runs the compute launches rank R of W would issue "
                          "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
+    ap.add_argument("--allow-host-staging", action="store_true",
+                    help="N>1: if no RCCL transport passes its start-up check, stage the halo planes through host memory over a "
+                         "gloo group instead of failing (a PCIe number, not an xGMI one; reported in config.halo_transport)")
+    ap.add_argument("--halo-transport", default="auto", choices=["auto", "c-abi", "torch"],
+                    help="N>1: auto = the C-ABI exchange (libneptune_hip.so issues ncclSend/ncclRecv itself), falling back to "
+                         "torch.distributed point-to-point ops if its start-up check fails; c-abi / torch force one")
     ap.add_argument("--fixed-input", action="store_true",
                     help="diagnostic: every step reads field 0 and writes field 1 (no ping-pong)")
     ap.add_argument("--builtin", action="store_true",
@@ -137,6 +143,12 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE JSON line.  RCCL prints a version banner and gloo its connection notes to file
+    # descriptor 1 from C code: keep a private handle on the real stdout for the JSON line and point fd 1 at stderr
+    # for everything else.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -220,42 +232,84 @@ def main():
             cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
         bufs[1].tensor.zero_()
         del probe
-    # Halo transport: RCCL send/recv between device buffers.  RCCL builds its point-to-point channels on
-    # first use (seconds): do that here, outside every timed or counted step.  If that first exchange
-    # fails on some rank (a node whose peer-to-peer path is unusable), ALL ranks switch to staging the planes
-    # through host memory over a gloo group: slower, still correct, and reported as config.halo_transport.
-    halo_group, transport = None, ("rccl" if world > 1 else "none")
+    # Halo transport.  RCCL builds its point-to-point channels on first use (seconds): do that here, outside every timed
+    # or counted step, and CHECK the result -- the ghost planes of the freshly filled field already hold the right global
+    # values, so: keep a copy, poison them, exchange, compare.  Order of preference:
+    #   1. the C-ABI path (include/neptune_hip.h section 8): libneptune_hip.so issues the grouped ncclSend/ncclRecv on
+    #      its own communication stream; a sharded step is ONE call into the library;
+    #   2. torch.distributed point-to-point ops on the default (nccl = RCCL) group;
+    #   3. only with --allow-host-staging: planes staged through host memory over a gloo group.
+    # A transport that fails or delivers wrong planes on ANY rank is dropped on ALL ranks (agreed through an all-reduce);
+    # if none is left the run ends with a non-zero exit code instead of printing a number.
+    halo_group, rccl_comm, transport = None, None, ("none" if world == 1 else None)
+
+    def ranks_agree(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def exchange_is_correct(do_exchange, what) -> bool:
+        t = bufs[0].tensor
+        lo, hi = sl.owned_planes()
+        ok = True
+        try:
+            want_lo, want_hi = t[:lo].clone(), t[hi:].clone()
+            t[:lo].fill_(float("nan"))
+            t[hi:].fill_(float("nan"))
+            torch.cuda.synchronize()
+            do_exchange(t)
+            torch.cuda.synchronize()
+            ok = bool(torch.equal(t[:lo], want_lo)) and bool(torch.equal(t[hi:], want_hi))
+            if not ok:
+                print(f"[bench] rank {rank}: {what}: ghost planes differ from the neighbours' planes", file=sys.stderr, flush=True)
+        except Exception as e:                      # noqa: BLE001 - whatever the transport raises means "unusable"
+            ok = False
+            print(f"[bench] rank {rank}: {what} failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
+        bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
+        torch.cuda.synchronize()
+        return ok
+
     if world > 1 and args.rehearse_on_one_gpu:
         transport = "gloo-host-staged (rehearsal)"
     elif world > 1 and emu is None:
-        ok = 1
-        try:
-            for w in slab_mod.exchange_halos(sl, bufs[0].tensor):
-                w.wait()
-            torch.cuda.synchronize()
-        except Exception as e:                      # noqa: BLE001 - anything RCCL raises here means "no P2P"
-            ok = 0
-            print(f"[bench] rank {rank}: RCCL halo exchange failed ({type(e).__name__}: {e}); proposing host staging",
-                  file=sys.stderr, flush=True)
-        # agree over RCCL's collectives (they do not use the point-to-point channels); the gloo group of the fallback
-        # is only created when it is needed -- gloo announces itself on stdout, which belongs to the one JSON line
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            halo_group, transport = dist.new_group(backend="gloo"), "gloo-host-staged (RCCL point-to-point failed)"
-    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=halo_group)
+        if args.halo_transport in ("auto", "c-abi"):
+            ok = True
+            try:
+                rccl_comm = slab_mod.RcclComm.from_process_group()
+            except Exception as e:                  # noqa: BLE001
+                ok = False
+                print(f"[bench] rank {rank}: C-ABI communicator: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            if ranks_agree(ok):
+                ok = exchange_is_correct(lambda t: rccl_comm.exchange(sl, t), "C-ABI halo exchange")
+            if ranks_agree(ok):
+                transport = "rccl, C ABI (neptune_hip_slab_apply: ncclSend/ncclRecv issued by libneptune_hip.so)"
+            else:
+                rccl_comm = None
+        if transport is None and args.halo_transport in ("auto", "torch"):
+            def torch_p2p(t):
+                for w in slab_mod.exchange_halos(sl, t):
+                    w.wait()
+            if ranks_agree(exchange_is_correct(torch_p2p, "torch.distributed point-to-point exchange")):
+                transport = "rccl, torch.distributed point-to-point"
+        if transport is None:
+            if not args.allow_host_staging:
+                if rank == 0:
+                    print("[bench] no RCCL halo transport passed its start-up check (see the messages above); refusing to "
+                          "fall back to host staging without --allow-host-staging", file=sys.stderr, flush=True)
+                dist.barrier()
+                dist.destroy_process_group()
+                sys.exit(3)
+            halo_group, transport = dist.new_group(backend="gloo"), "gloo-host-staged (no RCCL transport passed its check)"
+    elif emu is not None and (sl.r_lo or sl.r_hi):
+        # single-process emulation of rank R of W: the same C-ABI step with the rank itself as both neighbours (an RCCL
+        # communicator of one rank, loop-back send/recv): every stream operation and launch of the real step, with the
+        # halo planes copied on the device instead of crossing xGMI
+        rccl_comm = slab_mod.RcclComm(0, 1)
+        transport = "rccl, C ABI, loop-back to the same rank (emulation)"
+    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=halo_group, comm=rccl_comm,
+                               peers=(0, 0) if emu is not None else None)
     sharded = op
     stream_ptr = fields.current_stream_ptr()
-    if emu is not None:
-        # same launches as the real rank, ghosts simply left as initialised
-        def emu_step(fin, fout, _op=op):
-            rec = _op._records(fin, fout)
-            if rec["interior"] is not None:
-                _op._launch(rec, rec["interior"], fout, stream_ptr)
-            for e in rec["edges"]:
-                _op._launch(rec, e, fout, stream_ptr)
-        op = emu_step
-
     def barrier():
         if world > 1:
             dist.barrier()
@@ -305,6 +359,7 @@ def main():
     lib.neptune_hip_event_record(ev0, stream_ptr)
     for s in range(args.warmup, args.warmup + args.steps):
         step(s)
+    t_enqueued = time.perf_counter() - t0      # host time to enqueue the K steps (the device is still running them)
     lib.neptune_hip_event_record(ev1, stream_ptr)
     torch.cuda.synchronize()
     barrier()
@@ -385,6 +440,7 @@ def main():
                 "chunk": int(cfg.chunk),
                 "autotuned": autotuned,
                 "halo_transport": transport,
+                "host_enqueue_us_per_step": t_enqueued * 1e6 / args.steps,
                 "body": "lowered module (NeptuneIR text -> emitter -> hipcc)" if args.lowered else "library built-in (same statements)",
             },
             "hbm_GBps": achieved * world if world > 1 else achieved,
@@ -405,7 +461,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(body_name, gshape, esize, args.cpu_sample_planes)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
     lib.neptune_hip_event_destroy(ev0)
     lib.neptune_hip_event_destroy(ev1)

@@ -70,6 +70,8 @@ typedef struct {
 #define NEPTUNE_HIP_EOOB (-3)        /* an access would leave its input's box (UB in the
                                         reference, DataflowLowering.cpp:382-410: no
                                         bounds check; rejected here at plan time)      */
+#define NEPTUNE_HIP_ECOMM (-4)       /* RCCL / stream failure in the slab halo exchange; text in
+                                        neptune_hip_slab_last_error()                   */
 
 /* element types (the `element =` of !neptune_ir.field / !neptune_ir.temp,
  * include/Dialect/NeptuneIR/NeptuneIRTypes.td:22-33) */
@@ -181,6 +183,13 @@ int neptune_hip_set_slab(int64_t start, int64_t stop, int64_t ghost_lo, int64_t 
 int neptune_hip_clear_slab(void);
 /* out = {start, stop, ghost_lo, ghost_hi}; returns 1 if a slab is set, else 0 */
 int neptune_hip_get_slab(int64_t out[4]);
+/* Exchange beside interior for whole lowered functions: `event` (a hipEvent_t) marks a halo exchange of the call's
+ * inputs that is still in flight on another stream.  The next lowered function then launches the interior planes of
+ * its first stencil apply, makes its stream wait for the event, and launches the planes next to the ghosts; anything
+ * else that comes first (a store, a reduce, a pointwise apply over the ghost planes) waits for the event before it
+ * runs.  The event is consumed by that call (or by neptune_hip_clear_slab).  Needs a slab to be set. */
+int neptune_hip_set_slab_pending(void *event);
+void *neptune_hip_get_slab_pending(void);
 
 /* replaces the reference's neptune_rt_free (NeptunePETScRuntime.cpp:1825 -> free()):
  * frees either a malloc'ed host result or a device result of a lowered function */
@@ -316,6 +325,52 @@ void neptune_hip_event_sync(void *ev);
 double neptune_hip_event_elapsed_ms(void *start, void *stop);
 /* make `stream` wait for `ev` (stream-to-stream ordering without blocking the host) */
 void neptune_hip_stream_wait_event(void *stream, void *ev);
+
+/* ------------------------------------------------------------------------------------
+ * 8. slab decomposition across the GPUs of a node: halo exchange over RCCL, overlapped with the interior
+ *    (the reference has no counterpart -- every PETSc object lives on PETSC_COMM_SELF,
+ *    NeptunePETScRuntime.cpp:136,244,257).  One process per GPU.  Rank g owns planes [start_g, stop_g) of dim 0
+ *    and keeps `radius` ghost planes per existing neighbour in the SAME dense buffer:
+ *        local buffer = [ r_lo ghost planes | n_own owned planes | r_hi ghost planes ] x plane
+ *    so a halo is one contiguous run of memory, sent and received in place (ncclSend/ncclRecv, grouped, on a
+ *    communication stream).  No periodic wrap: at the global boundary r_lo / r_hi are 0 and the apply's copy-through
+ *    semantics hold (DataflowLowering.cpp:283-287, 382-410).
+ *    RCCL is loaded at the first call (dlopen librccl.so.1, reusing a copy already in the process); programs that
+ *    never call these entry points never load it.  Failures return NEPTUNE_HIP_ECOMM / NULL with the text in
+ *    neptune_hip_slab_last_error() -- they never fall back to another transport.
+ * ---------------------------------------------------------------------------------- */
+#define NEPTUNE_HIP_SLAB_ID_BYTES 128
+typedef struct neptune_hip_slab_comm neptune_hip_slab_comm_t;
+typedef struct neptune_hip_slab_plan neptune_hip_slab_plan_t;
+
+/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to every rank by any means */
+int neptune_hip_slab_unique_id(void *id_out);
+/* collective over the `world` ranks (ncclCommInitRank on the current device); id may be NULL when world == 1 */
+neptune_hip_slab_comm_t *neptune_hip_slab_comm_create(const void *id, int rank, int world);
+void neptune_hip_slab_comm_destroy(neptune_hip_slab_comm_t *comm);
+const char *neptune_hip_slab_last_error(void);
+
+/* Refresh the ghost planes of one local buffer on `stream`: the first r_lo owned planes go to peer_lo and its last
+ * planes arrive in my lower ghosts; likewise r_hi / peer_hi above (a side with 0 ghost planes is skipped, its peer is
+ * ignored).  Asynchronous.  peer == own rank is allowed (a loop-back used by the single-GPU tests). */
+int neptune_hip_halo_exchange(neptune_hip_slab_comm_t *comm, void *field, size_t plane_bytes, int64_t n_own,
+                              int r_lo, int r_hi, int peer_lo, int peer_hi, void *stream);
+
+/* One apply over this rank's slab, planned once.  `fn`: a lowered apply's geometry-level entry, or NULL to use
+ * built-in body `body`.  `local`: the geometry of the LOCAL buffers (boxes include the ghost planes; apply.bounds
+ * already clipped to the owned planes; the region is ignored).  radius = the apply's reach along dim 0.
+ * neptune_hip_slab_apply then runs, per call:
+ *     comm stream   : wait for the input on `compute_stream`, exchange the ghost planes of EVERY input
+ *     compute stream: interior planes (those that need no ghost data)                 -- overlaps the exchange
+ *     compute stream: wait for the exchange, then the `radius` edge planes per side that has a neighbour
+ * overlap = 0 makes the interior wait for the exchange as well (debugging).  Asynchronous on compute_stream. */
+neptune_hip_slab_plan_t *neptune_hip_slab_plan_create(neptune_hip_slab_comm_t *comm, neptune_hip_apply_fn fn, int body,
+                                                      int dtype, const neptune_hip_apply_geom_t *local, int radius,
+                                                      int r_lo, int r_hi, int peer_lo, int peer_hi,
+                                                      const neptune_hip_launch_cfg_t *cfg);
+int neptune_hip_slab_apply(neptune_hip_slab_plan_t *plan, const void *const *in, void *out, void *compute_stream,
+                           int overlap);
+void neptune_hip_slab_plan_destroy(neptune_hip_slab_plan_t *plan);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,9 @@ std::string report_json(const LowerInfo& info) {
     for (size_t i = 0; i < t.shape.size(); ++i) o << (i ? ", " : "") << t.shape[i];
     o << "], \"lb\": [";
     for (size_t i = 0; i < t.lb.size(); ++i) o << (i ? ", " : "") << t.lb[i];
-    o << "]}";
+    o << "]";
+    if (!t.scalar.empty()) o << ", \"scalar\": \"" << t.scalar << "\"";
+    o << "}";
   };
   for (size_t i = 0; i < info.signatures.size(); ++i) {
     const Signature& s = info.signatures[i];

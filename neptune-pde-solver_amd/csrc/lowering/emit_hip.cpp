@@ -387,6 +387,8 @@ struct Emitter {
   bool emit_function(const Function& f) {
     std::map<std::string, ValueInfo> vals;
     std::map<std::string, FusedReduce> fused_reduce;  // apply result -> how the consuming reduce evaluates it
+    std::map<std::string, int> scalar_kind;           // function-level scalars: 0 uniform, 1 bare reduce result, 2 derived from one
+    int returned_scalar_kind = -1;
     const int nargs = (int)f.arg_types.size();
     for (int i = 0; i < nargs; ++i) {
       ValueInfo vi;
@@ -651,6 +653,7 @@ struct Emitter {
             << dtype_macro(vt.elem) << ");\n";
         }
       } else if (n == "neptune_ir.reduce") {
+        scalar_kind[op.results[0]] = 1;   // under a slab view: this rank's partial sum
         const Type& in = op.types[0];
         std::string bx = "nullptr";
         if (op.attrs.count("bounds")) bx = "&" + new_box(op.attrs.at("bounds").bounds);
@@ -671,10 +674,25 @@ struct Emitter {
         // scalar arithmetic at function level (constants, reduce results): plain host statements
         static const std::map<std::string, int> none;
         if (!emit_op(op, o, "  ", none, none, nullptr)) return false;
+        // what a scalar means when the function runs on one slab of a decomposed field: 0 = the same on every rank
+        // (constants and arithmetic on them), 1 = a bare reduce result (ranks add up), 2 = computed FROM a partial sum
+        // (sqrt of it, a product of two, ...): not recoverable from the per-rank values
+        int kind = 0;
+        for (auto& a : op.operands) {
+          auto it = scalar_kind.find(a);
+          if (it != scalar_kind.end() && it->second != 0) kind = 2;
+        }
+        for (auto& r : op.results) scalar_kind[r] = kind;
       } else if (n == "neptune_ir.return" || n == "func.return" || n == "return") {
         if (op.operands.empty()) {
           o << "  return nl::Val{};\n";
         } else if (f.result_types[0].is_scalar()) {
+          auto it = scalar_kind.find(op.operands[0]);
+          const int kind = it == scalar_kind.end() ? 0 : it->second;
+          returned_scalar_kind = (returned_scalar_kind < 0 || returned_scalar_kind == kind) ? kind : 2;
+          if (kind == 2)
+            o << "  if (sc.has_ghosts()) nl::die(\"" << f.name << "\", \"slab mode: the returned scalar is computed from a reduce result, "
+              << "which is only this rank's partial sum -- return the bare reduce and finish the arithmetic after the ranks' sums are added\");\n";
           o << "  if (sret) *sret = (double)" << cname(op.operands[0]) << ";\n  return nl::Val{};\n";
         } else {
           const int root = vals[op.operands[0]].root_arg;
@@ -766,6 +784,7 @@ struct Emitter {
     for (auto& t : f.arg_types) sig.args.push_back(conv(t));
     sig.has_result = has_res;
     if (has_res) sig.result = conv(f.result_types[0]);
+    if (scalar_res) sig.result.scalar = returned_scalar_kind <= 0 ? "uniform" : (returned_scalar_kind == 1 ? "partial_sum" : "derived");
     info.signatures.push_back(sig);
     return true;
   }

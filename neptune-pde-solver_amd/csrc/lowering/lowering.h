@@ -23,6 +23,10 @@ struct SigType {
   int rank = 0;
   std::vector<int64_t> shape;  // -1 = dynamic
   std::vector<int64_t> lb;     // temp / field: logical origin
+  // scalar results only: what the value is when the function runs on one slab of a decomposed field --
+  // "uniform" (the same on every rank), "partial_sum" (a bare reduce: the ranks' values add up) or "derived"
+  // (computed from a partial sum: only right on a single rank)
+  std::string scalar;
 };
 struct Signature {
   std::string name;

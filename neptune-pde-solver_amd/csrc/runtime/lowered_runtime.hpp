@@ -80,7 +80,19 @@ class Scope {
   explicit Scope(const char* fn) : fn_(fn) {
     neptune_hip_init_default();
     slab_on_ = neptune_hip_get_slab(slab_) == 1;
+    pending_ = slab_on_ ? neptune_hip_get_slab_pending() : nullptr;
   }
+  // ---- a halo exchange of this call's inputs still in flight on another stream (neptune_hip_set_slab_pending) ----
+  bool pending() const { return pending_ != nullptr; }
+  // make this function's stream wait for it; afterwards every ghost plane of the inputs is valid
+  void wait_pending() {
+    if (!pending_) return;
+    NEPTUNE_HIP_CHECK(hipStreamWaitEvent(stream(), static_cast<hipEvent_t>(pending_), 0));
+    pending_ = nullptr;
+    neptune_hip_set_slab_pending(nullptr);   // consumed: later calls under the same slab view do not wait again
+  }
+  int64_t ghost_lo() const { return slab_on_ ? slab_[2] : 0; }
+  int64_t ghost_hi() const { return slab_on_ ? slab_[3] : 0; }
   // ---- slab view -------------------------------------------------------------------------
   bool slab() const { return slab_on_; }
   bool has_ghosts() const { return slab_on_ && (slab_[2] > 0 || slab_[3] > 0); }
@@ -214,6 +226,7 @@ class Scope {
   }
   // flush dirty host shadows; called by the exported wrapper before returning
   void finish() {
+    wait_pending();   // a function that never needed the ghost planes still returns with the exchange ordered before it
     if (async_mode() && !host_mode()) return;
     NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
     for (auto& h : host_args_)
@@ -222,6 +235,7 @@ class Scope {
   // result buffer for the caller: host malloc in host mode (caller free()s it), else the device
   // buffer itself (caller neptune_rt_free()s it)
   void* export_result(const Val& v) {
+    wait_pending();
     if (!(async_mode() && !host_mode())) NEPTUNE_HIP_CHECK(hipStreamSynchronize(stream()));
     void* owned = release(v);
     if (host_mode()) {
@@ -257,6 +271,7 @@ class Scope {
     return v.box.same_shape(b);
   }
   const char* fn_;
+  void* pending_ = nullptr;
   bool slab_on_ = false;
   int64_t slab_[4] = {0, 0, 0, 0};
   struct Owned { void* p; size_t bytes; };
@@ -350,6 +365,33 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const 
   out.stale_ghosts = sc.has_ghosts() && !whole_local;
   const void* ptrs[NIN];
   for (int k = 0; k < NIN; ++k) ptrs[k] = in[k]->dev;
+  if (sc.pending()) {
+    // The inputs' ghost planes are still being exchanged on another stream.  A stencil apply does its interior planes
+    // now -- they read owned planes only -- then waits, then does the planes next to the ghosts and the ghost planes
+    // themselves (copy-through); anything else waits first.
+    const int64_t n0 = result_box.ub[0] - result_box.lb[0];
+    const int64_t a = sc.ghost_lo() > 0 ? sc.ghost_lo() + halo0 : 0;
+    const int64_t b = n0 - (sc.ghost_hi() > 0 ? sc.ghost_hi() + halo0 : 0);
+    if (halo0 > 0 && !whole_local && b > a && !overlaps(out, *in[0])) {
+      neptune_hip_apply_geom_t gi = g;
+      gi.region_lb[0] = a;
+      gi.region_ub[0] = b;
+      rc = launch_apply<Body, T, RANK, NIN, FP>(body, &gi, ptrs, out.dev, sc.stream(), launch_override());
+      if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
+      sc.wait_pending();
+      const int64_t edges[2][2] = {{0, a}, {b, n0}};
+      for (auto& e : edges) {
+        if (e[1] <= e[0]) continue;
+        gi.region_lb[0] = e[0];
+        gi.region_ub[0] = e[1];
+        rc = launch_apply<Body, T, RANK, NIN, FP>(body, &gi, ptrs, out.dev, sc.stream(), launch_override());
+        if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
+      }
+      if (direct) sc.mark_dirty(*dest);
+      return out;
+    }
+    sc.wait_pending();
+  }
   rc = launch_apply<Body, T, RANK, NIN, FP>(body, &g, ptrs, out.dev, sc.stream(), launch_override());
   if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
   if (direct) sc.mark_dirty(*dest);
@@ -358,6 +400,7 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const 
 
 // neptune_ir.store (DataflowLowering.cpp:165-220)
 inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds_decl, int dtype) {
+  sc.wait_pending();   // a store may write planes the exchange is still sending
   int rc;
   Box clipped;
   const Box* bounds = bounds_decl;
@@ -389,6 +432,7 @@ static const int32_t kPointwiseRadius2[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_R
 // neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
 // slab mode: this rank's partial sum over its owned planes (the caller adds the ranks' results)
 inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, int dtype) {
+  sc.wait_pending();
   double r = 0.0;
   Box clipped;
   const Box* bounds = bounds_decl;
@@ -411,6 +455,7 @@ inline double run_apply_reduce_sum(Scope& sc, const Body& body, const Box& resul
                                    const Val* const* in,
                                    const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], int halo0,
                                    const Box* reduce_decl) {
+  sc.wait_pending();
   for (int k = 0; k < NIN; ++k)
     if (sc.has_ghosts() && halo0 > 0 && in[k]->stale_ghosts)
       die(sc.name(), "slab mode: neptune_ir.apply reads neighbouring planes of a value computed inside this call");

@@ -360,6 +360,7 @@ size_t neptune_hip_pool_cached_bytes(void) {
 
 static int64_t g_slab[4] = {0, 0, 0, 0};
 static bool g_slab_set = false;
+static void* g_slab_pending = nullptr;  // hipEvent_t of a halo exchange still in flight on another stream
 int neptune_hip_set_slab(int64_t start, int64_t stop, int64_t ghost_lo, int64_t ghost_hi) {
   if (stop < start || ghost_lo < 0 || ghost_hi < 0) return NEPTUNE_HIP_EINVAL;
   g_slab[0] = start; g_slab[1] = stop; g_slab[2] = ghost_lo; g_slab[3] = ghost_hi;
@@ -368,8 +369,15 @@ int neptune_hip_set_slab(int64_t start, int64_t stop, int64_t ghost_lo, int64_t 
 }
 int neptune_hip_clear_slab(void) {
   g_slab_set = false;
+  g_slab_pending = nullptr;
   return NEPTUNE_HIP_OK;
 }
+int neptune_hip_set_slab_pending(void* event) {
+  if (!g_slab_set) return NEPTUNE_HIP_EINVAL;
+  g_slab_pending = event;
+  return NEPTUNE_HIP_OK;
+}
+void* neptune_hip_get_slab_pending(void) { return g_slab_set ? g_slab_pending : nullptr; }
 int neptune_hip_get_slab(int64_t out[4]) {
   if (!g_slab_set) return 0;
   for (int i = 0; i < 4; ++i) out[i] = g_slab[i];

@@ -19,13 +19,15 @@ HEADER_PATH = REPO_ROOT / "include" / "neptune_hip.h"
 MAX_RANK = 3
 MAX_INPUTS = 4
 
-OK, EINVAL, EUNSUPPORTED, EOOB = 0, -1, -2, -3
+OK, EINVAL, EUNSUPPORTED, EOOB, ECOMM = 0, -1, -2, -3, -4
+SLAB_ID_BYTES = 128
 F64, F32 = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MARCH = 0, 1, 2
 FLAG_DIRECT_FLAT = 1   # direct kernel: flat one-lane-per-cell form instead of the rows form
 BODY_LAP2D5_F64, BODY_LAP3D7_F64, BODY_LAP3D27_F32, BODY_LAP1D3_F64 = 0, 1, 2, 3
 
-ERROR_NAMES = {EINVAL: "NEPTUNE_HIP_EINVAL", EUNSUPPORTED: "NEPTUNE_HIP_EUNSUPPORTED", EOOB: "NEPTUNE_HIP_EOOB"}
+ERROR_NAMES = {EINVAL: "NEPTUNE_HIP_EINVAL", EUNSUPPORTED: "NEPTUNE_HIP_EUNSUPPORTED", EOOB: "NEPTUNE_HIP_EOOB",
+               ECOMM: "NEPTUNE_HIP_ECOMM"}
 
 
 class NeptuneHipError(RuntimeError):
@@ -97,6 +99,8 @@ SIGNATURES = {
     "neptune_hip_set_slab": (_i, [_i64, _i64, _i64, _i64]),
     "neptune_hip_clear_slab": (_i, []),
     "neptune_hip_get_slab": (_i, [C.POINTER(C.c_int64)]),
+    "neptune_hip_set_slab_pending": (_i, [_vp]),
+    "neptune_hip_get_slab_pending": (_vp, []),
     "neptune_hip_check_geom": (_i, [_geom_p, _radius_p]),
     "neptune_hip_apply_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p]),
     "neptune_hip_apply_builtin_plan": (_i, [_i, _geom_p, _vpp, _vp, _cfg_p]),
@@ -123,6 +127,15 @@ SIGNATURES = {
     "neptune_hip_event_sync": (None, [_vp]),
     "neptune_hip_event_elapsed_ms": (_dbl, [_vp, _vp]),
     "neptune_hip_stream_wait_event": (None, [_vp, _vp]),
+    # section 8: slab decomposition over RCCL
+    "neptune_hip_slab_unique_id": (_i, [_vp]),
+    "neptune_hip_slab_comm_create": (_vp, [_vp, _i, _i]),
+    "neptune_hip_slab_comm_destroy": (None, [_vp]),
+    "neptune_hip_slab_last_error": (C.c_char_p, []),
+    "neptune_hip_halo_exchange": (_i, [_vp, _vp, _sz, _i64, _i, _i, _i, _i, _vp]),
+    "neptune_hip_slab_plan_create": (_vp, [_vp, _vp, _i, _i, _geom_p, _i, _i, _i, _i, _i, _cfg_p]),
+    "neptune_hip_slab_apply": (_i, [_vp, _vpp, _vp, _vp, _i]),
+    "neptune_hip_slab_plan_destroy": (None, [_vp]),
 }
 
 _lib = None

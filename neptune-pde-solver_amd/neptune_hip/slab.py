@@ -164,15 +164,83 @@ def exchange_halos(slab: Slab, t: torch.Tensor, group=None, ops: Optional[List[d
     return dist.batch_isend_irecv(ops)
 
 
+class RcclComm:
+    """The C-ABI communicator of include/neptune_hip.h section 8: libneptune_hip.so itself issues the grouped
+    ncclSend / ncclRecv of a halo exchange (no Python, no torch.distributed in the step).  One per process;
+    collective to create.  `peer_lo` / `peer_hi` default to rank -/+ 1."""
+
+    def __init__(self, rank: int, world: int, unique_id: Optional[bytes] = None):
+        import ctypes as C
+        from . import _capi
+        self._capi, self._C = _capi, C
+        self.lib = _capi.load()
+        self.rank, self.world = rank, world
+        buf = C.create_string_buffer(unique_id, _capi.SLAB_ID_BYTES) if unique_id is not None else None
+        self.ptr = self.lib.neptune_hip_slab_comm_create(buf, rank, world)
+        if not self.ptr:
+            raise RuntimeError("neptune_hip_slab_comm_create: " + self.last_error())
+
+    def last_error(self) -> str:
+        return (self.lib.neptune_hip_slab_last_error() or b"").decode()
+
+    @classmethod
+    def from_process_group(cls, group=None, device: Optional[torch.device] = None) -> "RcclComm":
+        """rank 0 draws the RCCL unique id and broadcasts it over the torch.distributed group (any backend);
+        every rank then joins the communicator on its current device"""
+        from . import _capi
+        import ctypes as C
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        lib = _capi.load()
+        idbuf = C.create_string_buffer(_capi.SLAB_ID_BYTES)
+        ok = 1
+        if rank == 0:
+            ok = 1 if lib.neptune_hip_slab_unique_id(idbuf) == 0 else 0
+        dev = device if device is not None else (torch.device("cuda") if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+        t = torch.tensor(list(idbuf.raw) + [ok], dtype=torch.uint8, device=dev)
+        if world > 1:
+            dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        raw = bytes(t.cpu().tolist())
+        if raw[-1] != 1:
+            raise RuntimeError("neptune_hip_slab_unique_id failed on rank 0: " + (lib.neptune_hip_slab_last_error() or b"").decode())
+        return cls(rank, world, raw[:-1])
+
+    def exchange(self, slab: "Slab", t: torch.Tensor, stream: Optional[int] = None,
+                 peer_lo: Optional[int] = None, peer_hi: Optional[int] = None) -> None:
+        """refresh the ghost planes of the dense local buffer `t` on `stream` (asynchronous)"""
+        if tuple(t.shape) != slab.local_shape or not t.is_contiguous() or not t.is_cuda:
+            raise ValueError("tensor is not this slab's dense local device buffer")
+        plane_bytes = t[0].numel() * t.element_size()
+        st = int(torch.cuda.current_stream().cuda_stream) if stream is None else stream
+        rc = self.lib.neptune_hip_halo_exchange(self.ptr, t.data_ptr(), plane_bytes, slab.n_own, slab.r_lo, slab.r_hi,
+                                                slab.rank - 1 if peer_lo is None else peer_lo,
+                                                slab.rank + 1 if peer_hi is None else peer_hi, st)
+        if rc != 0:
+            raise RuntimeError(f"neptune_hip_halo_exchange: {self._capi.ERROR_NAMES.get(rc, rc)}: {self.last_error()}")
+
+    def close(self) -> None:
+        if getattr(self, "ptr", None):
+            self.lib.neptune_hip_slab_comm_destroy(self.ptr)
+            self.ptr = None
+
+
 class ShardedApply:
     """One apply over a slab-decomposed field, exchange overlapped with the interior.  `body`: a built-in
     body id (neptune_hip._capi.BODY_*) or the geometry-level entry of a lowered module's apply
     (LoweredModule.geom_entry) -- any user stencil; `slab.radius` must be its reach along dim 0
-    (GeomEntry.halo0).  Several inputs: pass lists of fields; every input's ghost planes are exchanged."""
+    (GeomEntry.halo0).  Several inputs: pass lists of fields; every input's ghost planes are exchanged.
 
-    def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True, group=None):
+    Transport: `comm` = an RcclComm -> the whole step (exchange on a communication stream, interior, edge planes)
+    is ONE call into libneptune_hip.so (neptune_hip_slab_apply); without it the exchange goes through
+    torch.distributed point-to-point ops on `group` (RCCL for the default nccl group; a gloo group = staged through
+    host memory: the rehearsal path of the tests)."""
+
+    def __init__(self, slab: Slab, body: int, bounds: Box, cfg=None, overlap: bool = True, group=None,
+                 comm: Optional[RcclComm] = None, peers: Optional[Tuple[int, int]] = None):
         from . import apply as _apply  # GPU path only
         self.group = group        # process group of the halo exchange (None = default; a gloo group = host-staged)
+        self.rccl = comm
+        self.peers = peers if peers is not None else (slab.rank - 1, slab.rank + 1)
+        self._plans = {}
         self._apply = _apply
         self.slab = slab
         self.body = body
@@ -218,9 +286,43 @@ class ShardedApply:
         if rc < 0:
             raise self._apply._capi.NeptuneHipError(rc, getattr(self.body, "symbol", "neptune_hip_apply_builtin"))
 
+    def _cplan(self, fins, fout):
+        """the C-side plan for this number of inputs / element type (geometry only: independent of the buffers)"""
+        key = (len(fins), fout.dtype)
+        plan = self._plans.get(key)
+        if plan is None:
+            import ctypes as C
+            capi = self._apply._capi
+            lib = capi.load()
+            g = self._apply.geom_for(fins, fout, self.bounds)
+            is_entry = hasattr(self.body, "fn")
+            fn = C.cast(self.body.fn, C.c_void_p) if is_entry else None
+            plan = lib.neptune_hip_slab_plan_create(self.rccl.ptr, fn, -1 if is_entry else self.body, fout.dtype, C.byref(g),
+                                                    self.slab.radius, self.slab.r_lo, self.slab.r_hi, self.peers[0], self.peers[1],
+                                                    C.byref(self.cfg) if self.cfg is not None else None)
+            if not plan:
+                raise RuntimeError("neptune_hip_slab_plan_create: " + self.rccl.last_error())
+            self._plans[key] = plan
+        return plan
+
+    def __del__(self):
+        try:
+            lib = self._apply._capi.load()
+            for plan in self._plans.values():
+                lib.neptune_hip_slab_plan_destroy(plan)
+        except Exception:   # interpreter shutdown
+            pass
+
     def __call__(self, fin, fout) -> None:
         slab = self.slab
         st = int(self.compute.cuda_stream)
+        if self.rccl is not None:
+            fins = list(fin) if isinstance(fin, (list, tuple)) else [fin]
+            rc = self._apply._capi.load().neptune_hip_slab_apply(self._cplan(fins, fout), self._apply._in_array(fins), fout.ptr, st,
+                                                                 1 if self.overlap else 0)
+            if rc != 0:
+                raise RuntimeError(f"neptune_hip_slab_apply: {self._apply._capi.ERROR_NAMES.get(rc, rc)}: {self.rccl.last_error()}")
+            return
         rec = self._records(fin, fout)
         if slab.world == 1:
             self._launch(rec, rec["whole"], fout, st)
@@ -265,44 +367,98 @@ class ShardedModule:
     beyond the ghost planes it is given aborts: it would read outside its input).  A function whose
     applies are chained through a stencil (an apply reading neighbouring planes of a value computed in
     the same call) cannot run sharded -- it needs an exchange in the middle -- and aborts with a message
-    saying so.  No overlap of exchange and compute here: the built-in bodies' ShardedApply has that."""
+    saying so.
 
-    def __init__(self, module, slab: Slab, group=None):
+    Schedule (same as ShardedApply): the exchange runs on a communication stream and its completion event is handed to
+    the runtime (neptune_hip_set_slab_pending); the function's first stencil apply launches its interior planes, waits
+    for the event, then launches the planes next to the ghosts.  `comm` = an RcclComm selects the C-ABI transport;
+    overlap=False (or a gloo group, whose planes are staged through the host) exchanges first and synchronises."""
+
+    def __init__(self, module, slab: Slab, group=None, comm: Optional[RcclComm] = None, overlap: bool = True,
+                 peers: Optional[Tuple[int, int]] = None):
         from . import _capi
         self.module = module
         self.slab = slab
         self.group = group
+        self.rccl = comm            # C-ABI transport (RcclComm); None = torch.distributed point-to-point on `group`
+        self.overlap = overlap
+        self.peers = peers if peers is not None else (slab.rank - 1, slab.rank + 1)
         self._lib = _capi.load()
+        self._comm_stream = None    # created at the first overlapped call (needs a device)
+        self._ready = self._halo_done = None
 
     def local_empty(self, dtype=torch.float64, device="cuda") -> torch.Tensor:
         return torch.empty(self.slab.local_shape, dtype=dtype, device=device)
+
+    def _device_exchange(self, tensors) -> bool:
+        """start the halo exchange of `tensors` on the communication stream and leave its completion event with the
+        runtime (neptune_hip_set_slab_pending): the lowered function overlaps its first stencil apply's interior with
+        it.  Returns False when this transport cannot run beside the compute stream (gloo staging)."""
+        lib = self._lib
+        staged = self.rccl is None and dist.get_backend(self.group) == "gloo"
+        if staged or not self.overlap or not all(t.is_cuda for t in tensors):
+            return False
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+            self._ready, self._halo_done = lib.neptune_hip_event_create(), lib.neptune_hip_event_create()
+        cur = int(torch.cuda.current_stream().cuda_stream)
+        comm = int(self._comm_stream.cuda_stream)
+        lib.neptune_hip_event_record(self._ready, cur)          # the inputs are complete on the caller's stream
+        lib.neptune_hip_stream_wait_event(comm, self._ready)
+        if cur != 0:
+            lib.neptune_hip_stream_wait_event(None, self._ready)   # lowered functions launch on the null stream
+        if self.rccl is not None:
+            for t in tensors:
+                self.rccl.exchange(self.slab, t, stream=comm, peer_lo=self.peers[0], peer_hi=self.peers[1])
+        else:
+            with torch.cuda.stream(self._comm_stream):
+                for t in tensors:
+                    for w in exchange_halos(self.slab, t, self.group):
+                        w.wait()            # stream-ordered: the communication stream waits for RCCL, the host does not
+        lib.neptune_hip_event_record(self._halo_done, comm)
+        return True
 
     def call(self, name: str, *args, exchange: Optional[Sequence[int]] = None):
         """`exchange`: indices of the arguments whose ghost planes are refreshed before the call
         (default: every tensor argument but the first, the reference's @entry(out, in...) convention; pass
         () when the caller has already exchanged)"""
         slab = self.slab
+        res = self.module.signatures[name]["result"]
+        if slab.world > 1 and res and res["kind"] == "scalar" and res.get("scalar") == "derived":
+            raise ValueError(f"@{name} returns a scalar computed from a neptune_ir.reduce result; on a slab decomposition that "
+                             "result is only this rank's partial sum, so the function would be evaluated on it and the "
+                             "ranks' values could not be combined.  Return the bare reduce (ShardedModule adds the ranks' sums) "
+                             "and finish the arithmetic on the total.")
         if exchange is None:
             exchange = [i for i, a in enumerate(args) if i > 0 and hasattr(a, "shape")]
             if len(args) == 1:
                 exchange = [0]
-        if slab.world > 1:
-            for i in exchange:
-                t = getattr(args[i], "tensor", args[i])
-                for w in exchange_halos(slab, t, self.group):
-                    w.wait()
-            if any(getattr(getattr(a, "tensor", a), "is_cuda", False) for a in args):
-                torch.cuda.current_stream().synchronize()   # lowered functions launch on the null stream
+        pending = False
+        if (slab.r_lo or slab.r_hi) and len(exchange):
+            tensors = [getattr(args[i], "tensor", args[i]) for i in exchange]
+            pending = self._device_exchange(tensors)
+            if not pending:
+                for t in tensors:
+                    if self.rccl is not None and t.is_cuda:
+                        self.rccl.exchange(slab, t, peer_lo=self.peers[0], peer_hi=self.peers[1])
+                    else:
+                        for w in exchange_halos(slab, t, self.group):
+                            w.wait()
+                if any(getattr(getattr(a, "tensor", a), "is_cuda", False) for a in args):
+                    torch.cuda.current_stream().synchronize()   # lowered functions launch on the null stream
         rc = self._lib.neptune_hip_set_slab(slab.start, slab.stop, slab.r_lo, slab.r_hi)
         if rc != 0:
             raise ValueError("bad slab")
+        if pending:   # exchange beside the interior of the function's first stencil apply
+            self._lib.neptune_hip_set_slab_pending(self._halo_done)
         try:
             ret = self.module.call(name, *args)
         finally:
             self._lib.neptune_hip_clear_slab()
         sig = self.module.signatures[name]
-        if sig["result"] and sig["result"]["kind"] == "scalar" and slab.world > 1:
-            # a reduce returned this rank's partial sum over its owned planes
+        if sig["result"] and sig["result"]["kind"] == "scalar" and slab.world > 1 and sig["result"].get("scalar") != "uniform":
+            # a bare reduce returned this rank's partial sum over its owned planes: the ranks' values add up.  (A scalar
+            # computed FROM a reduce -- sqrt of it, a product of two -- never gets here: checked before the call.)
             t = torch.tensor([ret], dtype=torch.float64)
             if dist.get_backend(self.group) == "nccl":
                 t = t.cuda()

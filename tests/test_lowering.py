@@ -375,3 +375,39 @@ def test_elementary_functions_lower_and_are_flagged_inexact():
     assert got[i, j] == want and got[0, 5] == u[0, 5]
     with pytest.raises(lowering.LoweringError, match="unsupported operation 'math.erf'"):
         lowering.verify(text.replace("math.tanh %nb", "math.erf %nb"))
+
+
+def test_scalar_results_say_what_they_mean_on_a_slab():
+    """the lowering reports, per scalar-returning function, whether the value is a bare reduce (the ranks' partial sums
+    add up), the same on every rank, or computed FROM a reduce (only right on one rank) -- what ShardedModule needs to
+    combine or refuse it; the derived kind also aborts inside the lowered function when ghost planes are present"""
+    text = NORM.format(n0=6, n1=8, m0=5, m1=7)
+    src, report = lowering.to_hip(text)
+    assert report["signatures"][0]["result"]["scalar"] == "derived"          # sqrt(reduce)
+    assert "slab mode: the returned scalar is computed from a reduce result" in src
+    bare = text.replace("%r = math.sqrt %s : f64\n", "").replace("func.return %r", "func.return %s")
+    src_b, rep_b = lowering.to_hip(bare)
+    assert rep_b["signatures"][0]["result"]["scalar"] == "partial_sum" and "slab mode: the returned scalar" not in src_b
+    const = text.replace("%r = math.sqrt %s : f64", "%r = arith.constant 2.5 : f64")
+    _, rep_c = lowering.to_hip(const)
+    assert rep_c["signatures"][0]["result"]["scalar"] == "uniform"
+    # reduce + constant is derived too (the constant would be added once per rank)
+    plus = text.replace("%r = math.sqrt %s : f64", "%k = arith.constant 1.0 : f64\n    %r = arith.addf %s, %k : f64")
+    _, rep_p = lowering.to_hip(plus)
+    assert rep_p["signatures"][0]["result"]["scalar"] == "derived"
+
+
+def test_sharded_module_refuses_scalars_derived_from_a_partial_sum():
+    """sqrt(reduce(...)) summed over ranks is silently wrong; the call is refused before anything runs"""
+    from neptune_hip import slab
+
+    class FakeModule:
+        signatures = {"norm2": {"name": "norm2", "args": [], "result": {"kind": "scalar", "elem": "f64", "rank": 0, "scalar": "derived"}}}
+
+        def call(self, *a):
+            raise AssertionError("must not be called")
+    sl = slab.decompose(([0, 0], [8, 8]), 1, 0, 2)
+    sm = slab.ShardedModule.__new__(slab.ShardedModule)
+    sm.module, sm.slab, sm.group, sm._lib = FakeModule(), sl, None, None
+    with pytest.raises(ValueError, match="partial sum"):
+        sm.call("norm2")

@@ -135,3 +135,26 @@ def test_store_argument_checks_are_host_side(built_libs):
     rc = lib.neptune_hip_store_box(_capi.F64, 4, FAKE, a(0), a(16), FAKE + 4096, a(0), a(16), a(0), a(16), None)
     assert rc == _capi.EINVAL
     assert lib.neptune_hip_store_full(7, FAKE, FAKE + 4096, 4, None) == _capi.EINVAL
+
+
+def test_slab_plan_validation_needs_no_gpu(built_libs):
+    """neptune_hip_slab_plan_create decides everything on the host: malformed requests come back NULL with a reason;
+    a plan without ghost planes creates no stream and is destroyed again (no device involved)"""
+    import ctypes as C
+    from neptune_hip import _capi
+    from neptune_hip.geometry import make_geom
+    lib = _capi.load()
+    box = ([0, 0, 0], [10, 8, 128])
+    g = make_geom(box, ([1, 1, 1], [9, 7, 127]), [box])
+    err = lambda: (lib.neptune_hip_slab_last_error() or b"").decode()
+    make = lambda *a: lib.neptune_hip_slab_plan_create(*a)
+    assert not make(None, None, 99, _capi.F64, C.byref(g), 1, 0, 0, -1, -1, None) and "built-in body" in err()
+    assert not make(None, None, _capi.BODY_LAP3D7_F64, 7, C.byref(g), 1, 0, 0, -1, -1, None) and "element type" in err()
+    # ghost planes need a communicator; a slab of 10 planes cannot hold 6 + 6 ghost planes
+    assert not make(None, None, _capi.BODY_LAP3D7_F64, _capi.F64, C.byref(g), 1, 1, 1, 0, 0, None) and "communicator" in err()
+    assert not make(None, None, _capi.BODY_LAP3D7_F64, _capi.F64, C.byref(g), 1, 6, 6, 0, 0, None)
+    assert not make(None, None, _capi.BODY_LAP3D7_F64, _capi.F64, None, 1, 0, 0, -1, -1, None) and "geometry" in err()
+    plan = make(None, None, _capi.BODY_LAP3D7_F64, _capi.F64, C.byref(g), 1, 0, 0, -1, -1, None)
+    assert plan
+    lib.neptune_hip_slab_plan_destroy(plan)
+    assert lib.neptune_hip_halo_exchange(None, None, 0, 0, 0, 0, -1, -1, None) == _capi.EINVAL
