@@ -44,6 +44,10 @@ inline int geom_validate(const neptune_hip_apply_geom_t* g) {
   if (!g) return NEPTUNE_HIP_EINVAL;
   if (g->rank < 1 || g->rank > kMaxRank) return NEPTUNE_HIP_EINVAL;
   if (g->num_inputs < 1 || g->num_inputs > kMaxInputs) return NEPTUNE_HIP_EINVAL;
+  // bounds that are empty along ANY dimension make the reference's scf.for nest run zero trips
+  // (DataflowLowering.cpp:289-310): nothing is stored, so where the box lies along the other dimensions is irrelevant
+  bool empty = false;
+  for (int d = 0; d < g->rank; ++d) empty = empty || g->lb[d] >= g->ub[d];
   for (int d = 0; d < g->rank; ++d) {
     const int64_t n = g->out_ub[d] - g->out_lb[d];
     if (n <= 0) return NEPTUNE_HIP_EINVAL;
@@ -53,8 +57,7 @@ inline int geom_validate(const neptune_hip_apply_geom_t* g) {
       if (g->in_ub[k][d] - g->in_lb[k][d] <= 0) return NEPTUNE_HIP_EINVAL;
     if (g->lb[d] > g->ub[d]) return NEPTUNE_HIP_EINVAL;
     // the yielded scalar is stored at p - out_lb (:427-444): bounds must lie in the result box
-    if (g->lb[d] < g->ub[d] && (g->lb[d] < g->out_lb[d] || g->ub[d] > g->out_ub[d]))
-      return NEPTUNE_HIP_EOOB;
+    if (!empty && (g->lb[d] < g->out_lb[d] || g->ub[d] > g->out_ub[d])) return NEPTUNE_HIP_EOOB;
     if (g->region_lb[d] < 0 || g->region_ub[d] > n || g->region_lb[d] > g->region_ub[d])
       return NEPTUNE_HIP_EINVAL;
   }

@@ -428,8 +428,16 @@ struct Emitter {
         }
       }
       if ((op.name == "neptune_ir.return" || op.name == "func.return" || op.name == "return") && op.operands.size() == 1) {
+        // the caller's destination may only be handed down to a producer that is the LAST thing the function
+        // computes: an op between it and the return could still read an argument that aliases that destination
+        // (the reference gives every apply a private result, DataflowLowering.cpp:281)
         const int p = producer_of(op.operands[0]);
-        if (p >= 0 && vals[op.operands[0]].uses == 1) returned_producer = p;
+        bool clean = p >= 0 && vals[op.operands[0]].uses == 1;
+        for (int j = p + 1; clean && j < (int)oi; ++j) {
+          const std::string& nm = f.body.ops[j]->name;
+          if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "arith.constant")) clean = false;
+        }
+        if (clean) returned_producer = p;
       }
     }
 
@@ -440,6 +448,13 @@ struct Emitter {
     for (int i = 0; i < nargs; ++i) o << ", const nl::Val& " << cname(f.body.args[i].name);
     o << ", const nl::Val* dest, int* ret_arg, double* sret) {\n";
     o << "  (void)dest; (void)sret; if (ret_arg) *ret_arg = -1;\n";
+    if (returned_producer >= 0 && nargs > 0) {
+      // ... and never when it overlaps one of this function's own arguments (checked on the actual pointers): the
+      // producer would overwrite data the function was given to read
+      o << "  if (dest && (";
+      for (int i = 0; i < nargs; ++i) o << (i ? " || " : "") << "nl::overlaps(*dest, " << cname(f.body.args[i].name) << ")";
+      o << ")) dest = nullptr;\n";
+    }
     int apply_counter = 0;
     for (size_t oi = 0; oi < f.body.ops.size(); ++oi) {
       const Op& op = *f.body.ops[oi];

@@ -411,3 +411,46 @@ def test_sharded_module_refuses_scalars_derived_from_a_partial_sum():
     sm.module, sm.slab, sm.group, sm._lib = FakeModule(), sl, None, None
     with pytest.raises(ValueError, match="partial sum"):
         sm.call("norm2")
+
+
+CALLEE_READS_LATER = '''
+#l = #neptune_ir.location<"cell">
+!t = !neptune_ir.temp<element = f64, bounds = #neptune_ir.bounds<lb = [0], ub = [256]>, location = #l>
+!f = !neptune_ir.field<element = f64, bounds = #neptune_ir.bounds<lb = [0], ub = [256]>, location = #l>
+module {
+  neptune_ir.nonlinear_opdef @g : (!t, !t) -> !t {
+  ^bb0(%x: !t, %y: !t):
+    %a = neptune_ir.apply(%x) attributes {bounds = #neptune_ir.bounds<lb = [1], ub = [255]>} : (!t) -> !t {
+      ^bb0(%i: index, %xi: !t):
+        %l = neptune_ir.access %xi[-1] : !t -> f64
+        %r = neptune_ir.access %xi[1] : !t -> f64
+        %s = arith.addf %l, %r : f64
+        neptune_ir.yield %s : f64
+    }
+    %b = neptune_ir.apply(%y) attributes {bounds = #neptune_ir.bounds<lb = [1], ub = [255]>} : (!t) -> !t {
+      ^bb0(%i: index, %yi: !t):
+        %l = neptune_ir.access %yi[-1] : !t -> f64
+        neptune_ir.yield %l : f64
+    }
+    PLACEHOLDER
+  }
+}
+'''
+
+
+def test_destination_is_only_forwarded_to_the_last_producer_of_a_callee():
+    """ADVICE r1 (store elision through calls): the caller's destination field may be written directly only by a
+    producer that is the last thing the callee computes, and never when it overlaps one of the callee's arguments"""
+    # returned producer %a is followed by another apply (%b reads %y, which may alias the caller's destination)
+    early = CALLEE_READS_LATER.replace("PLACEHOLDER", "neptune_ir.return %a : !t")
+    src, _ = lowering.to_hip(early)
+    impl = src[src.index("static nl::Val g__impl(nl::Scope& sc"):]
+    impl = impl[:impl.index("\n}\n")]
+    assert "kTopRadius_g_0, nullptr," in impl and ", dest," not in impl          # %a gets a private result
+    # returned producer %b IS the last op: it may take the destination, guarded by the overlap check on the arguments
+    last = CALLEE_READS_LATER.replace("PLACEHOLDER", "neptune_ir.return %b : !t")
+    src2, _ = lowering.to_hip(last)
+    impl2 = src2[src2.index("static nl::Val g__impl(nl::Scope& sc"):]
+    impl2 = impl2[:impl2.index("\n}\n")]
+    assert "if (dest && (nl::overlaps(*dest, v_x) || nl::overlaps(*dest, v_y))) dest = nullptr;" in impl2
+    assert "kTopRadius_g_1, dest," in impl2 and "kTopRadius_g_0, nullptr," in impl2

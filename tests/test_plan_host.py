@@ -158,3 +158,26 @@ def test_slab_plan_validation_needs_no_gpu(built_libs):
     assert plan
     lib.neptune_hip_slab_plan_destroy(plan)
     assert lib.neptune_hip_halo_exchange(None, None, 0, 0, 0, 0, -1, -1, None) == _capi.EINVAL
+
+
+def test_bounds_empty_along_one_dimension_are_zero_trips_wherever_they_lie(built_libs):
+    """the reference's loop nest runs no iteration when ANY dimension of apply.bounds is empty
+    (DataflowLowering.cpp:289-310), so bounds that are empty along one dimension and leave the result box -- or the
+    footprint's reach -- along another are not an out-of-bounds plan"""
+    import ctypes as C
+    from neptune_hip import _capi
+    from neptune_hip.geometry import make_geom
+    lib = _capi.load()
+    box = ([0, 0], [16, 128])
+    radius = ((C.c_int32 * _capi.MAX_RANK) * _capi.MAX_INPUTS)()
+    for k in range(_capi.MAX_INPUTS):
+        for d in range(_capi.MAX_RANK):
+            radius[k][d] = 1 if k == 0 and d < 2 else -1
+    ok_geom = make_geom(box, ([1, 1], [15, 127]), [box])
+    assert lib.neptune_hip_check_geom(C.byref(ok_geom), radius) == _capi.OK
+    out_of_box = make_geom(box, ([1, 1], [15, 200]), [box])
+    assert lib.neptune_hip_check_geom(C.byref(out_of_box), radius) == _capi.EOOB
+    empty_and_out = make_geom(box, ([5, 1], [5, 200]), [box])          # dim 0 empty, dim 1 leaves the box
+    assert lib.neptune_hip_check_geom(C.byref(empty_and_out), radius) == _capi.OK
+    empty_and_reach = make_geom(box, ([0, 7], [16, 7]), [box])         # dim 1 empty, dim 0 would reach outside
+    assert lib.neptune_hip_check_geom(C.byref(empty_and_reach), radius) == _capi.OK
