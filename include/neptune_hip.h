@@ -277,6 +277,18 @@ int neptune_hip_reduce_sum(int dtype, int rank, const void *src, const int64_t *
 void *neptune_hip_reduce_workspace(void);
 
 /* ------------------------------------------------------------------------------------
+ * 6c. vector updates for device-resident Krylov loops
+ *    The reference's matrix-free solvers call the lowered operator from a host KSP loop over host Vecs
+ *    (NeptunePETScRuntime.cpp:182-230, 719-786).  With device pointers in the memref arguments the operator and the
+ *    dot products (reduce of an apply) already run without any host traffic; these two updates complete a solver
+ *    loop that never leaves the GPU (a run-time scalar cannot enter a NeptuneIR apply region: IsolatedFromAbove).
+ *    Element type of `a` follows dtype (rounded to float for F32).  Two roundings, no FMA.  Asynchronous.
+ *      axpy: y[i] = y[i] + a * x[i]          xpay: y[i] = x[i] + a * y[i]
+ * ---------------------------------------------------------------------------------- */
+int neptune_hip_axpy(int dtype, int64_t n, double a, const void *x, void *y, void *stream);
+int neptune_hip_xpay(int dtype, int64_t n, const void *x, double a, void *y, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * 7. helpers for tests and the bench (device-side, so 8 GiB fields never cross PCIe)
  * ---------------------------------------------------------------------------------- */
 /* Deterministic field: value depends only on (global linear index + index_offset, seed);

@@ -70,6 +70,20 @@ __global__ __launch_bounds__(256) void neptune_copy16_unrolled(const u32x4* __re
   }
 }
 
+// Krylov vector updates on device-resident vectors (the host KSP loop of the reference updates its
+// Vecs on the host, NeptunePETScRuntime.cpp:719-786).  NeptuneIR regions are IsolatedFromAbove, so a run-time scalar
+// such as CG's alpha cannot enter an apply; these two kernels are the missing piece for a solver loop that never leaves
+// the GPU.  Two roundings each (the product, then the sum), no FMA -- what numpy's `y += a * x` computes.
+//   AXPY: y[i] = y[i] + a * x[i]        XPAY: y[i] = x[i] + a * y[i]
+template <class T, bool XPAY>
+__global__ __launch_bounds__(256) void neptune_vec_update(int64_t n, T a, const T* __restrict__ x, T* __restrict__ y) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if constexpr (XPAY) { const T t = a * y[i]; y[i] = x[i] + t; }
+    else { const T t = a * x[i]; y[i] = y[i] + t; }
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void neptune_fill_hash(T* __restrict__ dst, int64_t count, int64_t index_offset,
                                                          uint64_t seed) {

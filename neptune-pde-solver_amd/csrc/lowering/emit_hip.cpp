@@ -422,7 +422,8 @@ struct Emitter {
           bool clean = true;  // nothing between producer and store may observe the field
           for (int j = p + 1; j < (int)oi; ++j) {
             const std::string& nm = f.body.ops[j]->name;
-            if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "arith.constant")) clean = false;
+            if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "neptune_ir.as_tensor" ||
+                  nm == "neptune_ir.from_tensor" || nm == "arith.constant")) clean = false;
           }
           if (clean) dest_of[p] = "&" + cname(field);
         }
@@ -435,7 +436,8 @@ struct Emitter {
         bool clean = p >= 0 && vals[op.operands[0]].uses == 1;
         for (int j = p + 1; clean && j < (int)oi; ++j) {
           const std::string& nm = f.body.ops[j]->name;
-          if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "arith.constant")) clean = false;
+          if (!(nm == "neptune_ir.wrap" || nm == "neptune_ir.unwrap" || nm == "neptune_ir.load" || nm == "neptune_ir.as_tensor" ||
+                  nm == "neptune_ir.from_tensor" || nm == "arith.constant")) clean = false;
         }
         if (clean) returned_producer = p;
       }
@@ -459,7 +461,8 @@ struct Emitter {
     for (size_t oi = 0; oi < f.body.ops.size(); ++oi) {
       const Op& op = *f.body.ops[oi];
       const std::string& n = op.name;
-      if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load") {
+      if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load" || n == "neptune_ir.as_tensor" ||
+          n == "neptune_ir.from_tensor") {
         ValueInfo vi;
         vi.type = op.types[1];
         vi.root_arg = vals[op.operands[0]].root_arg;

@@ -36,11 +36,12 @@ struct Type {
   Bounds bounds;               // Temp / Field
   std::string location;        // Temp / Field
   std::vector<int64_t> shape;  // MemRef; -1 = dynamic ('?')
+  bool tensor = false;         // MemRef spelled `tensor<...>` (as_tensor / from_tensor): a dense buffer all the same
   bool is_scalar() const { return kind == TypeKind::Scalar; }
   bool is_tempish() const { return kind == TypeKind::Temp || kind == TypeKind::Field; }
   int rank() const { return kind == TypeKind::MemRef ? (int)shape.size() : bounds.rank(); }
   bool operator==(const Type& o) const {
-    return kind == o.kind && elem == o.elem && bounds == o.bounds && location == o.location && shape == o.shape;
+    return kind == o.kind && elem == o.elem && bounds == o.bounds && location == o.location && shape == o.shape && tensor == o.tensor;
   }
   bool operator!=(const Type& o) const { return !(*this == o); }
   std::string str() const;

@@ -24,7 +24,7 @@ std::string Type::str() const {
              ", bounds = #neptune_ir.bounds<lb = [" + list(bounds.lb) + "], ub = [" + list(bounds.ub) +
              "]>, location = #neptune_ir.location<\"" + location + "\">>";
     case TypeKind::MemRef: {
-      std::string s = "memref<";
+      std::string s = tensor ? "tensor<" : "memref<";
       for (auto d : shape) s += (d < 0 ? std::string("?") : std::to_string(d)) + "x";
       return s + elem + ">";
     }
@@ -94,7 +94,10 @@ bool tokenize(const std::string& s, std::vector<Tok>& out, Diag& diag) {
       if (j < n && (is_id_start(s[j]) || (sigil && std::isdigit((unsigned char)s[j])))) {
         while (j < n && is_id_char(s[j])) ++j;
         std::string id = s.substr(i, j - i);
-        if (id == "memref") {
+        // `tensor<4x8xf64>` (the operand / result of neptune_ir.as_tensor / from_tensor) is read like a static memref:
+        // after bufferization a ranked tensor IS a dense buffer, and the reference keeps the two ops as casts
+        // (lib/Passes/DataflowLowering.cpp:705-733)
+        if (id == "memref" || id == "tensor") {
           size_t k = j;
           while (k < n && std::isspace((unsigned char)s[k])) ++k;
           if (k < n && s[k] == '<') {
@@ -105,7 +108,7 @@ bool tokenize(const std::string& s, std::vector<Tok>& out, Diag& diag) {
               else if (s[m] == '>' && --depth == 0) break;
             }
             if (m >= n) { diag.fail(line, "unterminated memref type"); return false; }
-            out.push_back({Tk::MemRef, s.substr(k + 1, m - k - 1), line});
+            out.push_back({Tk::MemRef, (id == "tensor" ? "T:" : "") + s.substr(k + 1, m - k - 1), line});
             i = m + 1;
             continue;
           }
@@ -235,6 +238,7 @@ struct Parser {
     if (k.kind == Tk::MemRef) {
       ty.kind = TypeKind::MemRef;
       std::string s = k.text;
+      if (s.compare(0, 2, "T:") == 0) { ty.tensor = true; s = s.substr(2); }
       size_t pos = 0;
       std::vector<std::string> parts;
       while (true) {
@@ -377,8 +381,9 @@ struct Parser {
       op.types = {a, b};
       return true;
     }
-    if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load") {
-      // $x attr-dict `:` type($x) `->` type($result)   (NeptuneIROps.td:31-33, 55-57, 79-81)
+    if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load" || n == "neptune_ir.as_tensor" ||
+        n == "neptune_ir.from_tensor") {
+      // $x attr-dict `:` type($x) `->` type($result)   (NeptuneIROps.td:31-33, 55-57, 79-81, 553-556, 588-591)
       op.operands.push_back(next().text);
       if (is("{")) { if (!parse_attr_dict(op.attrs)) return false; }
       Type a, b;

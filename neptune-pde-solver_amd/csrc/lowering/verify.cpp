@@ -257,7 +257,25 @@ struct Verifier {
                                                       "arith.subf", "arith.subi", "arith.mulf", "arith.constant"};
         if (!allowed.count(n)) { diag.fail(op.line, "'" + n + "' op operation not allowed in linear_opdef body"); return false; }
       }
-      if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load") {
+      if (n == "neptune_ir.as_tensor" || n == "neptune_ir.from_tensor") {
+        // temp <-> ranked tensor of the temp's shape and element type (NeptuneIROps.td:540-556, 575-591); like the
+        // reference, which keeps both as casts (DataflowLowering.cpp:705-733), they are aliases of the same buffer
+        Type in;
+        if (!lookup(sc, op, op.operands[0], in)) return false;
+        if (in != op.types.at(0)) { diag.fail(op.line, "'" + n + "' op operand type does not match its declared type"); return false; }
+        const Type& out = op.types.at(1);
+        const Type& tmp = n == "neptune_ir.as_tensor" ? in : out;
+        const Type& ten = n == "neptune_ir.as_tensor" ? out : in;
+        if (tmp.kind != TypeKind::Temp || ten.kind != TypeKind::MemRef || !ten.tensor) {
+          diag.fail(op.line, "'" + n + "' op converts between a temp and a ranked tensor");
+          return false;
+        }
+        if (tmp.elem != ten.elem) { diag.fail(op.line, "'" + n + "' op element type mismatch"); return false; }
+        bool same = tmp.rank() == ten.rank();
+        for (int d = 0; same && d < tmp.rank(); ++d) same = ten.shape[d] == tmp.bounds.ub[d] - tmp.bounds.lb[d];
+        if (!same) { diag.fail(op.line, "'" + n + "' op tensor shape must equal the extents of the temp's bounds"); return false; }
+        sc[op.results.at(0)] = out;
+      } else if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load") {
         Type in;
         if (!lookup(sc, op, op.operands[0], in)) return false;
         if (in != op.types.at(0)) { diag.fail(op.line, "'" + n + "' op operand type does not match its declared type"); return false; }

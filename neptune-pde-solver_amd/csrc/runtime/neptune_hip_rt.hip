@@ -154,6 +154,25 @@ int autotune_launches(L&& launch, bool march_planned, int rank, int nv, hipStrea
 }  // namespace
 
 
+namespace {
+template <bool XPAY>
+int vec_update(int dtype, int64_t n, double a, const void* x, void* y, void* stream) {
+  if (!x || !y || n < 0) return NEPTUNE_HIP_EINVAL;
+  if (n == 0) return NEPTUNE_HIP_OK;
+  
+  const int64_t want = (n + 255) / 256;
+  const uint32_t blocks = (uint32_t)(want < 256 * 32 ? want : 256 * 32);
+  if (dtype == NEPTUNE_HIP_F64)
+    hipLaunchKernelGGL((neptune_vec_update<double, XPAY>), dim3(blocks), dim3(256), 0, as_stream(stream), n, a, (const double*)x, (double*)y);
+  else if (dtype == NEPTUNE_HIP_F32)
+    hipLaunchKernelGGL((neptune_vec_update<float, XPAY>), dim3(blocks), dim3(256), 0, as_stream(stream), n, (float)a, (const float*)x, (float*)y);
+  else
+    return NEPTUNE_HIP_EINVAL;
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+}  // namespace
+
 extern "C" {
 
 // ---------------------------------------------------------------- runtime
@@ -682,6 +701,14 @@ int neptune_hip_reduce_sum(int dtype, int rank, const void* src, const int64_t* 
     *result = (double)h;
   }
   return NEPTUNE_HIP_OK;
+}
+
+// ---------------------------------------------------------------- Krylov vector updates
+int neptune_hip_axpy(int dtype, int64_t n, double a, const void* x, void* y, void* stream) {
+  return vec_update<false>(dtype, n, a, x, y, stream);
+}
+int neptune_hip_xpay(int dtype, int64_t n, const void* x, double a, void* y, void* stream) {
+  return vec_update<true>(dtype, n, a, x, y, stream);
 }
 
 // ---------------------------------------------------------------- helpers

@@ -112,6 +112,8 @@ SIGNATURES = {
     "neptune_hip_store_full": (_i, [_i, _vp, _vp, _i64, _vp]),
     "neptune_hip_store_box": (_i, [_i, _i, _vp, _i64p, _i64p, _vp, _i64p, _i64p, _i64p, _i64p, _vp]),
     "neptune_hip_reduce_sum": (_i, [_i, _i, _vp, _i64p, _i64p, _i64p, _i64p, C.POINTER(C.c_double), _vp]),
+    "neptune_hip_axpy": (_i, [_i, _i64, _dbl, _vp, _vp, _vp]),
+    "neptune_hip_xpay": (_i, [_i, _i64, _vp, _dbl, _vp, _vp]),
     "neptune_hip_fill_hash": (_i, [_i, _vp, _i64, _i64, _u64, _vp]),
     "neptune_hip_hash_value": (_dbl, [_i, _i64, _u64]),
     "neptune_hip_count_mismatch": (_i64, [_i, _vp, _vp, _i64, _vp]),

@@ -145,7 +145,7 @@ def tokenize(src: str) -> List[Tok]:
             raise OracleError(f"cannot tokenize at offset {i}: {src[i:i+30]!r}")
         kind = m.lastgroup
         text = m.group()
-        if kind == "id" and text == "memref":
+        if kind == "id" and text in ("memref", "tensor"):   # tensor<...>: as_tensor / from_tensor casts (:705-733)
             # memref<?x?xf64> : take the bracketed text raw ('?x?xf64' is not tokenizable)
             j = m.end()
             while j < n and src[j].isspace():
@@ -505,7 +505,7 @@ class Parser:
             self.expect("->")
             op.types.append(self.parse_type())
             return op
-        if name in ("neptune_ir.wrap", "neptune_ir.unwrap", "neptune_ir.load"):
+        if name in ("neptune_ir.wrap", "neptune_ir.unwrap", "neptune_ir.load", "neptune_ir.as_tensor", "neptune_ir.from_tensor"):
             op.operands = [self.next().text]
             if self.peek().text == "{":
                 op.attrs = self.parse_attr_dict()
@@ -808,8 +808,9 @@ class Module:
             env[name] = val
         for op in f.body.ops:
             n = op.name
-            if n in ("neptune_ir.wrap", "neptune_ir.load", "neptune_ir.unwrap"):
-                # aliases of the same buffer (:131-159); only the logical origin may change
+            if n in ("neptune_ir.wrap", "neptune_ir.load", "neptune_ir.unwrap", "neptune_ir.as_tensor", "neptune_ir.from_tensor"):
+                # aliases of the same buffer (:131-159; as_tensor / from_tensor stay casts, :705-733); only the logical
+                # origin may change
                 src: Buffer = env[op.operands[0]]
                 dst_ty = op.types[1]
                 if isinstance(dst_ty, TempType):

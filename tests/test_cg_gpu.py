@@ -65,3 +65,57 @@ def test_examples_run(built_libs, tmp_path):
                           capture_output=True, text=True, timeout=600)
     assert wave.returncode == 0 and "stable: True" in wave.stdout and "('step', 'march')" in wave.stdout, \
         wave.stdout[-1500:] + wave.stderr[-3000:]
+
+
+def test_c_krylov_loop_with_device_pointers_through_the_reference_abi(built_libs, tmp_path, monkeypatch):
+    """SURVEY 8(f) row 2 without PCIe in the loop: tests/thunk_abi/cg_device.c is a 50-iteration CG in C that reaches
+    @matmult / @dot with dlsym and the expanded-memref ABI (NeptunePETScRuntime.cpp:182-230) but hands over DEVICE
+    pointers; vector updates are neptune_hip_axpy / _xpay.  Checked against the same 50 iterations driven by the oracle
+    (dot products: device tree sum vs serial sum, so iterates agree to rounding, not bit for bit), and the block pool
+    must stay empty: a staged host argument would have left its device shadow there."""
+    import os
+    import subprocess
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    import cg_matrix_free as ex
+    from neptune_hip import _capi, lowering
+    shape = (14, 12, 128)
+    iters = 50
+    text = ex.module_text(shape)
+    mod = lowering.compile_module(text)
+    rng = np.random.default_rng(11)
+    b = np.zeros(shape)
+    b[1:-1, 1:-1, 1:-1] = rng.random(tuple(n - 2 for n in shape))
+    (tmp_path / "b.bin").write_bytes(b.tobytes())
+    exe = tmp_path / "cg_device"
+    libdir = _capi.LIB_PATH.parent
+    subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Werror", "-I", str(helpers.REPO / "include"),
+                    str(helpers.REPO / "tests/thunk_abi/cg_device.c"), "-L", str(libdir), "-lneptune_hip", "-ldl",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    p = subprocess.run([str(exe), str(mod.path), *[str(n) for n in shape], str(iters), str(tmp_path / "b.bin"),
+                        str(tmp_path / "x.bin")], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = p.stdout.strip().splitlines()
+    rs_dev = [float.fromhex(l.split()[3]) for l in lines if l.startswith("it ")]
+    assert len(rs_dev) == iters
+    assert lines[-1] == "pool_cached_bytes 0"                      # nothing was staged through a device shadow
+    x_dev = np.frombuffer((tmp_path / "x.bin").read_bytes(), dtype=np.float64).reshape(shape)
+    # the same loop on the oracle (numpy: `alpha * p` rounds, then the sum rounds -- the two roundings of the kernels)
+    m = oracle.Module.parse(text)
+    x, r = np.zeros(shape), b.copy()
+    pv, ap = r.copy(), np.zeros(shape)
+    rs = float(m.call("dot", r, r))
+    rs_ref = []
+    for _ in range(iters):
+        m.call("matmult", ap, pv)
+        alpha = rs / float(m.call("dot", pv, ap))
+        x += alpha * pv
+        r += (-alpha) * ap
+        rs_new = float(m.call("dot", r, r))
+        pv = r + (rs_new / rs) * pv
+        rs = rs_new
+        rs_ref.append(rs)
+    assert rs_dev[-1] < 1e-12 * rs_dev[0] or rs_dev[-1] < 1e-20            # it converged
+    # early iterations agree to rounding; later ones drift apart as CG amplifies the summation-order differences
+    np.testing.assert_allclose(rs_dev[:10], rs_ref[:10], rtol=1e-9)
+    assert np.abs(x_dev - x).max() <= 1e-8 * np.abs(x).max()
+    assert np.all(x_dev[0] == 0) and np.all(x_dev[:, :, -1] == 0)

@@ -454,3 +454,55 @@ def test_destination_is_only_forwarded_to_the_last_producer_of_a_callee():
     impl2 = impl2[:impl2.index("\n}\n")]
     assert "if (dest && (nl::overlaps(*dest, v_x) || nl::overlaps(*dest, v_y))) dest = nullptr;" in impl2
     assert "kTopRadius_g_1, dest," in impl2 and "kTopRadius_g_0, nullptr," in impl2
+
+
+TENSOR_CASTS = '''
+#l = #neptune_ir.location<"cell">
+!t = !neptune_ir.temp<element = f64, bounds = #neptune_ir.bounds<lb = [2, 0], ub = [10, 128]>, location = #l>
+module {
+  neptune_ir.linear_opdef @A : (!t) -> !t {
+  ^bb0(%u: !t):
+    %r = neptune_ir.apply(%u) attributes {bounds = #neptune_ir.bounds<lb = [3, 1], ub = [9, 127]>} : (!t) -> !t {
+      ^bb0(%i: index, %j: index, %a: !t):
+        %n = neptune_ir.access %a[-1, 0] : !t -> f64
+        %s = neptune_ir.access %a[1, 0] : !t -> f64
+        %v = arith.addf %n, %s : f64
+        neptune_ir.yield %v : f64
+    }
+    neptune_ir.return %r : !t
+  }
+  func.func @f(%x: tensor<8x128xf64>) -> tensor<8x128xf64> {
+    %a = neptune_ir.from_tensor %x : tensor<8x128xf64> -> !t
+    %b = neptune_ir.apply_linear @A(%a) : (!t) -> !t
+    %c = neptune_ir.as_tensor %b : !t -> tensor<8x128xf64>
+    func.return %c : tensor<8x128xf64>
+  }
+}
+'''
+
+
+def test_as_tensor_and_from_tensor_are_casts_of_the_same_buffer():
+    """neptune_ir.as_tensor / from_tensor (NeptuneIROps.td:540-591) stay casts in the reference's dataflow lowering
+    (DataflowLowering.cpp:705-733); here a ranked tensor is read like a static memref and both ops alias the buffer"""
+    import numpy as np
+    src, report = lowering.to_hip(TENSOR_CASTS)
+    assert 'sc.alias(v_x, kBox' in src and '"neptune_ir.from_tensor"' in src and '"neptune_ir.as_tensor"' in src
+    sig = {s["name"]: s for s in report["signatures"]}["f"]
+    assert sig["args"][0]["kind"] == "memref" and sig["args"][0]["shape"] == [8, 128]
+    with pytest.raises(lowering.LoweringError, match="tensor shape must equal the extents"):
+        lowering.verify(TENSOR_CASTS.replace("%c = neptune_ir.as_tensor %b : !t -> tensor<8x128xf64>",
+                                             "%c = neptune_ir.as_tensor %b : !t -> tensor<8x64xf64>")
+                        .replace("func.return %c : tensor<8x128xf64>", "func.return %c : tensor<8x64xf64>")
+                        .replace("-> tensor<8x128xf64> {", "-> tensor<8x64xf64> {"))
+    with pytest.raises(lowering.LoweringError, match="element type mismatch"):
+        lowering.verify(TENSOR_CASTS.replace("%a = neptune_ir.from_tensor %x : tensor<8x128xf64> -> !t",
+                                             "%a = neptune_ir.from_tensor %x : tensor<8x128xf32> -> !t")
+                        .replace("@f(%x: tensor<8x128xf64>)", "@f(%x: tensor<8x128xf32>)"))
+    # the oracle agrees on what the function computes: the operator applied to the buffer read with origin [2, 0]
+    from helpers import oracle
+    m = oracle.Module.parse(TENSOR_CASTS)
+    x = helpers.hash_field((8, 128), np.float64, seed=9)
+    got = m.call("f", x)
+    want = x.copy()
+    want[1:7, 1:127] = x[0:6, 1:127] + x[2:8, 1:127]
+    assert helpers.bits_equal(np.asarray(got), want)
