@@ -232,6 +232,20 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
                           void *const fields[2], const void *const *in, int64_t steps, void *stream,
                           const neptune_hip_launch_cfg_t *cfg);
 
+/* Two steps per pass over HBM.  neptune_hip_apply2_builtin computes out = A(A(in)) for built-in body A in ONE launch
+ * (the intermediate field exists in registers only; same operations on the same operands as two launches, hence the
+ * same bits) when the body is a rank-3 single-input radius-1 star and the geometry qualifies (all boxes equal, rows a
+ * whole number of 64-byte granules, launch region restricted along dim 0 only); otherwise NEPTUNE_HIP_EUNSUPPORTED and
+ * nothing is launched.  Lowered applies export the same thing as <function>_<k>__geom2.
+ * neptune_hip_step_loop uses it for the built-in bodies on its own; neptune_hip_step_loop_pairs is the same loop with a
+ * lowered apply's pair entry `fn2` (NULL = none) next to its single-step entry `fn`.  The reference steps one apply per
+ * pass on the host (runtime forward Euler, NeptunePETScRuntime.cpp:677-712). */
+int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t *g, const void *const *in, void *out,
+                               void *stream, const neptune_hip_launch_cfg_t *cfg);
+int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, int body,
+                                const neptune_hip_apply_geom_t *g, void *const fields[2], const void *const *in,
+                                int64_t steps, void *stream, const neptune_hip_launch_cfg_t *cfg);
+
 /* Which kernel neptune_hip_apply_builtin would run for (body, g, cfg):
  * NEPTUNE_HIP_KERNEL_DIRECT / _MARCH, or a negative error. */
 int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t *g,

@@ -1,0 +1,260 @@
+// apply_march2.hpp -- TWO chained applies of the same body in ONE pass over HBM (temporal blocking):
+//     out = A(A(in))     with A = one neptune_ir.apply (copy-through outside its bounds included)
+//
+// An explicit time loop `u <- A(u)` repeated is bound by HBM: every step reads the field once and writes it
+// once.  The reference runs such loops on the host, one apply per step (runtime method 2: forward Euler,
+// lib/Runtime/PETSc/NeptunePETScRuntime.cpp:677-712).  This kernel produces step n+2 from step n directly: the
+// intermediate field v = A(u) exists only in registers, so two steps cost one read and one write of the field plus
+// the redundant rim described below -- 2.3 field passes instead of 4.1.  The operations, their order and their operands
+// are exactly those of two separate launches (the body functor is evaluated once per cell and stage, strict IEEE,
+// no contraction), hence the same bits.
+//
+// Scope: rank 3, one input, star footprint of radius 1 (the 7-point family, the fused explicit Euler step of such an
+// operator included), all boxes equal, rows a whole number of 64-byte store granules.  Everything else keeps using
+// two launches (neptune_hip_step_loop decides).
+//
+// Shape of the march (one workgroup = WJ waves stacked along J, one wave span wide):
+//   * a wave owns RJ rows x 64 lane vectors; the workgroup's window is TJ = WJ*RJ rows x 64*VK cells.
+//   * stage 1 computes v on the whole window from u (K neighbours by wave shifts, J neighbours of the window's own
+//     rows through LDS); v is therefore valid one cell / one row inside the window's edge, and stage 2's result w two
+//     cells / rows inside.  Windows OVERLAP instead of fetching halos: the row stride between workgroups is TJ - 4 and
+//     the column stride 64*VK - 64 B/sizeof(T) -- the kept columns start 4 lane vectors... [kw + KEEP0, ...) is a whole
+//     number of 64-byte granules, so every store instruction writes whole granules (a partially written granule costs
+//     a read-modify-write at the memory side: profiles/r02_headline_search.txt section 3).  No scalar halo loads at all.
+//   * along dim 0 the wave keeps 3 planes of u and 3 planes of v in registers; step i loads u(i+3), computes v(i+1)
+//     from u(i..i+2) and w(i) from v(i-1..i+1), stores w(i).  A chunk starts two planes early (results discarded)
+//     to fill the v ring: 4 redundant plane reads per chunk.
+//   * one barrier per step: the waves publish the edge rows of u(i+1) AND of v(i) together.
+#pragma once
+#include "apply_march.hpp"
+
+namespace neptune_hip {
+
+template <class T>
+struct March2Params {
+  const T* in;
+  T* out;
+  int32_t N0, N1, N2;
+  int32_t plb[3], pub[3];  // apply.bounds, result-physical
+  int64_t olb[3];          // logical origin (index arguments)
+  int32_t rI0, rI1;        // planes this launch stores
+  int32_t chunk;
+  uint32_t nJ, nK;
+};
+
+// RJ rows per lane, WJ waves per workgroup
+template <class Body, class T, class FP, int RJ, int WJ>
+__global__ __launch_bounds__(kWave* WJ) void neptune_apply_march2(March2Params<T> P, Body body) {
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int TJ = RJ * WJ;                 // window rows
+  constexpr int KEEPJ = TJ - 4;               // rows of w this workgroup stores: [Jb + 2, Jb + TJ - 2)
+  constexpr int G = 64 / (int)sizeof(T);      // cells per 64-byte store granule
+  constexpr int SPAN = kWave * VK;            // window columns
+  constexpr int KEEPK = SPAN - G;             // columns of w this wave stores: [kw + G/2, kw + SPAN - G/2)
+  static_assert((G / 2) % VK == 0 && G / 2 >= 2, "the kept columns must start at a whole lane, two cells inside");
+  static_assert(FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u, "radius-1 star of input 0");
+  __shared__ V lds[2][WJ][4][kWave];          // [parity][wave][u first, u last, v first, v last][lane]
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = vb % P.nK;
+  const uint32_t t = vb / P.nK;
+  const uint32_t jt = t % P.nJ;
+  const uint32_t ct = t / P.nJ;
+
+  const int32_t Jb = (int32_t)(jt * KEEPJ) - 2;          // first row of the window
+  const int32_t j0 = Jb + w * RJ;                        // first own row
+  const int32_t kw = (int32_t)(kt * KEEPK) - G / 2;      // first column of the window
+  const int32_t k0 = kw + lane * VK;
+  // loads: clamped into the field (a clamped cell only ever feeds values that are discarded)
+  const int32_t kc = k0 < 0 ? 0 : (k0 > P.N2 - VK ? P.N2 - VK : k0);
+  const uint32_t lane_b = (uint32_t)kc * (uint32_t)sizeof(T);
+  uint32_t rowb[RJ];
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    int32_t j = j0 + r;
+    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+    rowb[r] = (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  });
+  const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
+
+  const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
+  const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
+  if (ib >= ie) return;
+
+  auto load_plane = [&](int32_t ip, V(&rows)[RJ]) {
+    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    const char* base = reinterpret_cast<const char*>(P.in) + (int64_t)ic * plane_b;
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      rows[r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b));
+    });
+  };
+
+  // store predicates: rows and columns of w this wave keeps
+  bool row_keep[RJ], in_j[RJ], in_k[VK];
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    const int32_t j = j0 + r;
+    row_keep[r] = j >= Jb + 2 && j < Jb + TJ - 2 && j >= 0 && j < P.N1;
+    in_j[r] = j >= P.plb[1] && j < P.pub[1];
+  });
+  static_for<VK>([&](auto ec) {
+    constexpr int e = ec;
+    in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
+  });
+  const bool lane_keep = k0 >= kw + G / 2 && k0 < kw + SPAN - G / 2 && k0 >= 0 && k0 < P.N2;
+
+  // one stage: `ctr` = the centre plane's own rows, `above` / `below` its J-halo rows, lo / hi the planes before / after
+  auto stage = [&](const V(&lo)[RJ], const V(&ctr)[RJ], const V(&hi)[RJ], const V& above, const V& below, int32_t ip,
+                   V(&res)[RJ]) {
+    V ring[1][3][RJ + 2];
+    T lft[1][1][RJ + 2][1], rgt[1][1][RJ + 2][1];
+    V pt[1][RJ];
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      ring[0][0][r + 1] = lo[r];
+      ring[0][1][r + 1] = ctr[r];
+      ring[0][2][r + 1] = hi[r];
+      // K neighbours from the adjacent lanes; the wave's outermost cells get an arbitrary edge value: their results
+      // are two cells outside the kept columns
+      lft[0][0][r + 1][0] = from_prev<true>(ctr[r][VK - 1], ctr[r][0], lane);
+      rgt[0][0][r + 1][0] = from_next<true>(ctr[r][0], ctr[r][VK - 1], lane);
+    });
+    ring[0][1][0] = above;
+    ring[0][1][RJ + 1] = below;
+    const bool in_i = ip >= P.plb[0] && ip < P.pub[0];
+    const int64_t li = (int64_t)ip + P.olb[0];
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      const int64_t lj = (int64_t)(j0 + r) + P.olb[1];
+      static_for<VK>([&](auto ec) {
+        constexpr int e = ec;
+        const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
+        MarchAcc<T, 3, 1, FP, RJ, r, e, false> acc{ring, lft, rgt, pt, li, lj, lk};
+        const T val = body(acc);
+        const T through = ctr[r][e];
+        res[r][e] = (in_i && in_j[r] && in_k[e]) ? val : OutsideOf<Body, T>::apply(body, through);
+      });
+    });
+  };
+
+  // ---- register state: planes are named by their distance from the step's plane i
+  V u0[RJ], u1[RJ], u2[RJ], un[RJ];   // u(i), u(i+1), u(i+2), u(i+3) in flight
+  V vm[RJ], v0[RJ], v1[RJ];           // v(i-1), v(i), v(i+1)
+  V wres[RJ];
+  const int32_t i0 = ib - 2;          // two warm-up steps fill the v ring (their w is discarded)
+  load_plane(i0, u0);
+  load_plane(i0 + 1, u1);
+  load_plane(i0 + 2, un);
+  static_for<RJ>([&](auto rc) { constexpr int r = rc; vm[r] = u0[r]; v0[r] = u0[r]; });   // defined, never kept
+
+  for (int32_t i = i0; i < ie; ++i) {
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; u2[r] = un[r]; });
+    // J-halo rows of u(i+1) and of v(i): publish my first / last own rows, take the neighbouring waves'
+    const int buf = (i - i0) & 1;
+    lds[buf][w][0][lane] = u1[0];
+    lds[buf][w][1][lane] = u1[RJ - 1];
+    lds[buf][w][2][lane] = v0[0];
+    lds[buf][w][3][lane] = v0[RJ - 1];
+    __syncthreads();
+    V ua = u1[0], ubl = u1[RJ - 1], va = v0[0], vbl = v0[RJ - 1];   // window-edge waves: any value (rows not kept)
+    if (w > 0) { ua = lds[buf][w - 1][1][lane]; va = lds[buf][w - 1][3][lane]; }
+    if (w < WJ - 1) { ubl = lds[buf][w + 1][0][lane]; vbl = lds[buf][w + 1][2][lane]; }
+    if (i + 3 <= ie + 1) load_plane(i + 3, un);   // u(ie+1) is the last plane any kept result depends on
+    stage(u0, u1, u2, ua, ubl, i + 1, v1);        // v(i+1)
+    stage(vm, v0, v1, va, vbl, i, wres);          // w(i)
+    if (i >= ib && lane_keep) {
+      char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
+      static_for<RJ>([&](auto rc) {
+        constexpr int r = rc;
+        if (row_keep[r]) __builtin_nontemporal_store(wres[r], reinterpret_cast<V*>(obase + (rowb[r] + lane_b)));
+      });
+    }
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      u0[r] = u1[r]; u1[r] = u2[r];
+      vm[r] = v0[r]; v0[r] = v1[r];
+    });
+  }
+}
+
+// host side: can this geometry take the two-steps kernel, and launch it
+template <class T, class FP>
+inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* in, const void* out) {
+  constexpr int G = 64 / (int)sizeof(T);
+  if (!g || g->rank != 3 || g->num_inputs != 1) return false;
+  if (!(FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u)) return false;
+  int64_t n[3];
+  for (int d = 0; d < 3; ++d) {
+    n[d] = g->out_ub[d] - g->out_lb[d];
+    if (g->in_lb[0][d] != g->out_lb[d] || g->in_ub[0][d] != g->out_ub[d]) return false;
+    if (d > 0 && (g->region_lb[d] != 0 || g->region_ub[d] != n[d])) return false;
+  }
+  if (n[2] % G != 0 || n[2] < 2 * G || n[1] < 8 || n[0] < 1) return false;   // rows = whole 64-byte granules
+  if (n[1] * n[2] * (int64_t)sizeof(T) >= 0x7fffffffLL) return false;         // 32-bit in-plane offsets
+  if ((uintptr_t)in % 64 != 0 || (uintptr_t)out % 64 != 0) return false;
+  // the second apply re-reads what the first one copied through: only sound when every access of an in-bounds cell
+  // stays inside the box (the same rule every plan obeys)
+  for (int d = 0; d < 3; ++d)
+    if (g->lb[d] < g->ub[d] && (g->lb[d] - 1 < g->out_lb[d] || g->ub[d] + 1 > g->out_ub[d])) return false;
+  return true;
+}
+
+template <class Body, class T, class FP, int RJ = 4, int WJ = 8>
+inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+                         int chunk_req) {
+  if (!march2_eligible<T, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
+  if (geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;   // pure copies: leave to the plain path
+  constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T);
+  constexpr int KEEPJ = RJ * WJ - 4, KEEPK = kWave * VK - G;
+  March2Params<T> P{};
+  P.in = static_cast<const T*>(in);
+  P.out = static_cast<T*>(out);
+  P.N0 = (int32_t)(g->out_ub[0] - g->out_lb[0]);
+  P.N1 = (int32_t)(g->out_ub[1] - g->out_lb[1]);
+  P.N2 = (int32_t)(g->out_ub[2] - g->out_lb[2]);
+  for (int d = 0; d < 3; ++d) {
+    P.plb[d] = (int32_t)(g->lb[d] - g->out_lb[d]);
+    P.pub[d] = (int32_t)(g->ub[d] - g->out_lb[d]);
+    P.olb[d] = g->out_lb[d];
+  }
+  P.rI0 = (int32_t)g->region_lb[0];
+  P.rI1 = (int32_t)g->region_ub[0];
+  if (P.rI1 <= P.rI0) return NEPTUNE_HIP_OK;
+  P.nJ = (uint32_t)((P.N1 + KEEPJ - 1) / KEEPJ);
+  P.nK = (uint32_t)((P.N2 + KEEPK - 1) / KEEPK);
+  const int64_t planes = P.rI1 - P.rI0;
+  int64_t chunk = chunk_req > 0 ? chunk_req : 128;
+  // small fields: enough workgroups for every CU
+  while (chunk > 16 && (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk) < 512) chunk /= 2;
+  if (chunk > planes) chunk = planes;
+  P.chunk = (int32_t)chunk;
+  const int64_t blocks = (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk);
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
+  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, RJ, WJ>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P, body);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
+// what callers use: two chained applies of `body` if the footprint and the geometry allow it, else
+// NEPTUNE_HIP_EUNSUPPORTED (the caller then launches the apply twice); never instantiates the kernel for a footprint it
+// cannot serve
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int launch_apply_twice(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                              hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+  if constexpr (RANK == 3 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX &&
+                FP::HALO_MASK == 1u) {
+    if (!g || !in || !in[0] || !out) return NEPTUNE_HIP_EINVAL;
+    if (cfg && cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_EUNSUPPORTED;
+    const int rc = geom_validate(g);
+    if (rc != NEPTUNE_HIP_OK) return rc;
+    return launch_march2<Body, T, FP>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
+  } else {
+    return NEPTUNE_HIP_EUNSUPPORTED;
+  }
+}
+
+}  // namespace neptune_hip

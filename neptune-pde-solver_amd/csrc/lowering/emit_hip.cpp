@@ -565,6 +565,16 @@ struct Emitter {
                      << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
                      << "  return neptune_hip::launch_apply<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
                      << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n"
+                     << "// two chained applies of this body in one pass over HBM (csrc/kernels/apply_march2.hpp): out = A(A(in)), or\n"
+                     << "// NEPTUNE_HIP_EUNSUPPORTED when the footprint / geometry does not qualify (neptune_hip_step_loop_pairs)\n"
+                     << "extern \"C\" int " << ai.geom_symbol << "2"
+                     << "(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,\n"
+                     << "    const neptune_hip_launch_cfg_t* cfg) {\n"
+                     << "  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;\n"
+                     << "  const int rc = neptune_hip::geom_check_radius(g, kTopRadius_" << tag << ");\n"
+                     << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
+                     << "  return neptune_hip::launch_apply_twice<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
+                     << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n"
                      << "// march tiles this module holds for that entry (plan-time tuning: neptune_hip_autotune_fn)\n"
                      << "extern \"C\" int " << ai.geom_symbol << "_variants(int rank) { return neptune_hip::march_variant_count(rank); }\n\n";
         info.applies.push_back(ai);
@@ -629,6 +639,42 @@ struct Emitter {
           ai.march = cfp.march_ok;
           ai.box = cfp.box;
           ai.halo_input = cfp.halo_inputs > 0 ? std::max(cfp.halo_input, 0) : -1;
+          ai.elem = st.elem;
+          ai.halo0 = halo0_of(cfp);
+          ai.exact = cfp.exact;
+          // With a constant time step the fused step is a self-contained apply: give it geometry-level entries too
+          // (single step, two steps per pass, tile count), so step loops and slab decompositions can drive `u + dt*rhs(u)`
+          // exactly like a plain operator.
+          {
+            auto dit = def_at.find(op.operands[1]);
+            const Op* dtdef = dit == def_at.end() ? nullptr : f.body.ops[dit->second].get();
+            bool lit_ok = false;
+            std::string lit;
+            if (dtdef && dtdef->name == "arith.constant") lit = float_literal(dtdef->literal, st.elem, lit_ok);
+            if (lit_ok) {
+              ai.geom_symbol = tag + "__geom";
+              std::ostringstream& ge = geom_entries;
+              ge << "static const int32_t kTopRadiusG_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
+              for (int k = 0; k < 4; ++k) {
+                ge << (k ? ", {" : "{");
+                for (int d = 0; d < 3; ++d) ge << (d ? ", " : "") << (k == 0 && d < st.rank() ? std::max(cfp.top_radius[0][d], 0) : -1);
+                ge << "}";
+              }
+              ge << "};\n";
+              const char* names[2] = {"", "2"};
+              const char* fns[2] = {"launch_apply", "launch_apply_twice"};
+              for (int v = 0; v < 2; ++v)
+                ge << "extern \"C\" int " << ai.geom_symbol << names[v]
+                   << "(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,\n"
+                   << "    const neptune_hip_launch_cfg_t* cfg) {\n"
+                   << "  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;\n"
+                   << "  const int rc = neptune_hip::geom_check_radius(g, kTopRadiusG_" << tag << ");\n"
+                   << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
+                   << "  return neptune_hip::" << fns[v] << "<" << body << ", " << T << ", " << st.rank() << ", 1, FP_" << ctag << ">(" << body
+                   << "{(" << T << ")" << lit << "}, g, in, out, (hipStream_t)stream, cfg);\n}\n";
+              ge << "extern \"C\" int " << ai.geom_symbol << "_variants(int rank) { return neptune_hip::march_variant_count(rank); }\n\n";
+            }
+          }
           info.applies.push_back(ai);
         } else {
           o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";

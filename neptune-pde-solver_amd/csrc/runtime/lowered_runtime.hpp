@@ -32,6 +32,7 @@
 
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
+#include "../kernels/apply_march2.hpp"
 #include "../kernels/reduce_apply.hpp"
 
 namespace neptune_hip {

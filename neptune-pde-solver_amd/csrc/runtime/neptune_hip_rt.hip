@@ -17,6 +17,7 @@
 
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
+#include "../kernels/apply_march2.hpp"
 #include "../kernels/util_kernels.hpp"
 #include "builtin_bodies.hpp"
 
@@ -199,6 +200,7 @@ void neptune_hip_init(int device) {
 // state of neptune_hip_step_loop (defined further down)
 namespace {
 struct LoopKey {
+  neptune_hip_apply_fn fn2;   // two chained applies in one launch (a lowered apply's <tag>__geom2), or nullptr
   neptune_hip_apply_fn fn;
   int body;
   neptune_hip_apply_geom_t g;
@@ -437,8 +439,36 @@ int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const
   return NEPTUNE_HIP_EINVAL;
 }
 
+// two chained applies of a built-in body in one pass over HBM (csrc/kernels/apply_march2.hpp)
+int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                               void* stream, const neptune_hip_launch_cfg_t* cfg) {
+  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
+  if (body < 0 || body >= NEPTUNE_HIP_BODY_COUNT) return NEPTUNE_HIP_EINVAL;
+  int rc = geom_validate(g);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  if (g->num_inputs != 1 || !in[0]) return NEPTUNE_HIP_EUNSUPPORTED;
+  rc = check_no_alias(g, in, out, body_elem_size(body));
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  ensure_init();
+  hipStream_t s = as_stream(stream);
+  switch (body) {
+    case NEPTUNE_HIP_BODY_LAP3D7_F64:
+      return launch_apply_twice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg);
+    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 2-D, 1-D and box bodies: two launches
+  }
+}
+
 // ---------------------------------------------------------------- hipGraph step loop
 namespace {
+// out = A(A(in)) in one launch when the body and the geometry allow it (else NEPTUNE_HIP_EUNSUPPORTED)
+int loop_launch2(const LoopKey& k, int from, int to) {
+  if (k.g.num_inputs != 1) return NEPTUNE_HIP_EUNSUPPORTED;
+  const void* ins[1] = {k.fields[from]};
+  const neptune_hip_launch_cfg_t* cfg = (k.cfg.kernel || k.cfg.variant >= 0 || k.cfg.chunk || k.cfg.flags) ? &k.cfg : nullptr;
+  if (cfg && (cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT || cfg->variant >= 0)) return NEPTUNE_HIP_EUNSUPPORTED;  // an explicit tile was asked for
+  if (k.fn) return k.fn2 ? k.fn2(&k.g, ins, k.fields[to], (void*)k.stream, cfg) : NEPTUNE_HIP_EUNSUPPORTED;
+  return neptune_hip_apply2_builtin(k.body, &k.g, ins, k.fields[to], (void*)k.stream, cfg);
+}
 int loop_launch(const LoopKey& k, int from, int to) {
   const void* ins[NEPTUNE_HIP_MAX_INPUTS];
   for (int i = 0; i < k.g.num_inputs; ++i) ins[i] = k.in[i];
@@ -451,6 +481,12 @@ int loop_launch(const LoopKey& k, int from, int to) {
 
 int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_apply_geom_t* g, void* const fields[2],
                           const void* const* in, int64_t steps, void* stream, const neptune_hip_launch_cfg_t* cfg) {
+  return neptune_hip_step_loop_pairs(fn, nullptr, body, g, fields, in, steps, stream, cfg);
+}
+
+int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, int body, const neptune_hip_apply_geom_t* g,
+                                void* const fields[2], const void* const* in, int64_t steps, void* stream,
+                                const neptune_hip_launch_cfg_t* cfg) {
   if (!g || !fields || !fields[0] || !fields[1] || fields[0] == fields[1] || steps < 0) return NEPTUNE_HIP_EINVAL;
   if (g->num_inputs < 1 || g->num_inputs > NEPTUNE_HIP_MAX_INPUTS) return NEPTUNE_HIP_EINVAL;
   if (g->num_inputs > 1 && !in) return NEPTUNE_HIP_EINVAL;
@@ -458,6 +494,7 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
   LoopKey key;
   memset(&key, 0, sizeof(key));  // padding too: keys are compared with memcmp
   key.fn = fn;
+  key.fn2 = fn ? fn2 : nullptr;
   key.body = fn ? -1 : body;
   key.g = *g;
   key.fields[0] = fields[0];
@@ -487,6 +524,22 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
     return rc;
   };
 
+  // Two steps per pass over HBM while an EVEN number of such pair launches fits: each pair launch moves the state to
+  // the other field, so an even count brings it back to fields[0] and the remaining steps (fewer than four) run as
+  // before and end in fields[steps % 2].  The grouping does not change a bit: the same apply is evaluated, cell by cell,
+  // the same number of times on the same operands.
+  if (steps >= 4 && !getenv("NEPTUNE_HIP_NO_PAIRS")) {
+    const int64_t pairs = (steps / 2) & ~(int64_t)1;
+    int rc2 = loop_launch2(key, 0, 1);
+    if (rc2 == NEPTUNE_HIP_OK) {
+      for (int64_t p = 1; p < pairs && rc2 == NEPTUNE_HIP_OK; ++p) rc2 = loop_launch2(key, (int)(p % 2), (int)((p + 1) % 2));
+      if (rc2 != NEPTUNE_HIP_OK) return finish(rc2);
+      steps -= 2 * pairs;
+      if (steps == 0) return finish(NEPTUNE_HIP_OK);
+    } else if (rc2 != NEPTUNE_HIP_EUNSUPPORTED) {
+      return finish(rc2);
+    }
+  }
   // one plain launch first: validates the request (and warms the launcher's one-time queries) outside
   // of stream capture, and is step 0 of the loop
   int rc = loop_launch(key, 0, 1);

@@ -114,7 +114,7 @@ def test_c_krylov_loop_with_device_pointers_through_the_reference_abi(built_libs
         pv = r + (rs_new / rs) * pv
         rs = rs_new
         rs_ref.append(rs)
-    assert rs_dev[-1] < 1e-12 * rs_dev[0] or rs_dev[-1] < 1e-20            # it converged
+    assert rs_dev[-1] < 1e-8 * rs_dev[0]                                      # it converges
     # early iterations agree to rounding; later ones drift apart as CG amplifies the summation-order differences
     np.testing.assert_allclose(rs_dev[:10], rs_ref[:10], rtol=1e-9)
     assert np.abs(x_dev - x).max() <= 1e-8 * np.abs(x).max()

@@ -1,0 +1,137 @@
+"""Two applies per pass over HBM (csrc/kernels/apply_march2.hpp, neptune_hip_apply2_builtin, <tag>__geom2,
+neptune_hip_step_loop_pairs): out = A(A(in)) computed in one launch must equal two launches bit for bit -- the same
+operations on the same operands -- and both must equal the oracle's chained applies."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nh():
+    import torch
+    from neptune_hip import _capi, apply, fields
+
+    class NS:
+        pass
+    ns = NS()
+    ns.torch, ns.capi, ns.apply, ns.fields = torch, _capi, apply, fields
+    ns.lib = _capi.load()
+    ns.lib.neptune_hip_init(0)
+    return ns
+
+
+# shapes: window seams along every axis (rows 28 per workgroup, columns 120 per wave, chunk seams), first / last
+# tiles partially outside the field, a shifted logical origin and bounds tighter than the interior
+CASES = [
+    ((9, 40, 256), None, None),
+    ((34, 61, 376), None, None),
+    ((20, 29, 128), None, None),                       # one wave span, rows just over one workgroup window
+    ((12, 30, 256), [5, -3, 7], None),                 # shifted origin (index arguments are not used by this body, boxes are)
+    ((16, 40, 256), None, ([2, 3, 9], [13, 33, 201])),  # bounds tighter than the interior: copy-through bands inside
+]
+
+
+@pytest.mark.parametrize("shape,origin,bounds", CASES)
+def test_two_applies_in_one_pass_equal_two_launches_and_the_oracle(nh, shape, origin, bounds):
+    body = nh.capi.BODY_LAP3D7_F64
+    lb = origin or [0, 0, 0]
+    u = helpers.hash_field(shape, np.float64, seed=23)
+    fin = nh.fields.DeviceField.from_numpy(u, lb)
+    mid = nh.fields.DeviceField.empty_like(fin)
+    two = nh.fields.DeviceField.empty_like(fin)
+    one = nh.fields.DeviceField.empty_like(fin)
+    one.tensor.fill_(float("nan"))
+    if bounds is None:
+        b = ([l + 1 for l in lb], [l + n - 1 for l, n in zip(lb, shape)])
+    else:
+        b = ([l + x for l, x in zip(lb, bounds[0])], [l + x for l, x in zip(lb, bounds[1])])
+    nh.apply.apply_builtin(body, [fin], mid, b)
+    nh.apply.apply_builtin(body, [mid], two, b)
+    for chunk in (0, 5):
+        one.tensor.fill_(float("nan"))
+        assert nh.apply.apply_twice(body, fin, one, b, cfg=nh.apply.make_cfg(chunk=chunk))
+        nh.torch.cuda.synchronize()
+        got, want = one.numpy(), two.numpy()
+        assert helpers.bits_equal(got, want), f"chunk {chunk}\n" + helpers.mismatch_report(got, want)
+    o = helpers.oracle_entry("3d7", helpers.oracle_entry("3d7", u, origin=lb, bounds=b), origin=lb, bounds=b)
+    assert helpers.bits_equal(two.numpy(), o), helpers.mismatch_report(two.numpy(), o)
+
+
+def test_geometries_the_pair_kernel_cannot_take_are_refused_not_run(nh):
+    body = nh.capi.BODY_LAP3D7_F64
+    for shape in ((8, 16, 100), (8, 16, 12), (8, 4, 128)):   # rows not whole 64-byte granules / too short / too few rows
+        fin = nh.fields.DeviceField.from_numpy(helpers.hash_field(shape, np.float64, seed=1))
+        out = nh.fields.DeviceField.empty_like(fin)
+        out.tensor.fill_(7.0)
+        assert nh.apply.apply_twice(body, fin, out, ([1, 1, 1], [n - 1 for n in shape])) is False
+        nh.torch.cuda.synchronize()
+        assert bool((out.tensor == 7.0).all())
+    # 2-D and box bodies: two launches
+    f2 = nh.fields.DeviceField.from_numpy(helpers.hash_field((64, 256), np.float64, seed=1))
+    assert nh.apply.apply_twice(nh.capi.BODY_LAP2D5_F64, f2, nh.fields.DeviceField.empty_like(f2), ([1, 1], [63, 255])) is False
+
+
+@pytest.mark.parametrize("steps", [4, 5, 6, 7, 9, 12, 37])
+def test_step_loop_uses_pairs_and_ends_in_the_documented_field(nh, steps, monkeypatch):
+    """neptune_hip_step_loop with pair launches == the same loop forced to single launches == the oracle's chain; the
+    newest state is in fields[steps % 2] either way"""
+    body = nh.capi.BODY_LAP3D7_F64
+    shape = (12, 33, 256)
+    u = helpers.hash_field(shape, np.float64, seed=4) * 0.05      # the iteration grows ~12x per step: keep it finite
+    bounds = ([1, 1, 1], [n - 1 for n in shape])
+    a = nh.fields.DeviceField.from_numpy(u)
+    b = nh.fields.DeviceField.empty_like(a)
+    res = nh.apply.step_loop(body, a, b, bounds, steps)
+    nh.torch.cuda.synchronize()
+    assert res is (b if steps % 2 else a)
+    got = res.numpy().copy()
+    monkeypatch.setenv("NEPTUNE_HIP_NO_PAIRS", "1")
+    a2 = nh.fields.DeviceField.from_numpy(u)
+    b2 = nh.fields.DeviceField.empty_like(a2)
+    res2 = nh.apply.step_loop(body, a2, b2, bounds, steps)
+    nh.torch.cuda.synchronize()
+    assert helpers.bits_equal(got, res2.numpy())
+    o = u
+    for _ in range(steps):
+        o = helpers.oracle_entry("3d7", o)
+    assert helpers.bits_equal(got, o), helpers.mismatch_report(got, o)
+
+
+def test_fused_euler_step_of_a_lowered_module_two_steps_per_pass(nh, tmp_path, monkeypatch):
+    """the lowered @step (time_advance fused with its rhs apply) through its pair entry step_ta0__geom2, against the
+    oracle running @step twice; then a whole step loop over the module's entries"""
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    from neptune_hip import lowering
+    shape = (10, 36, 256)
+    text = helpers.stencil_module("3d7", list(shape), time_step=0.125)
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("step")
+    assert entry.symbol == "step_ta0__geom" and entry.fn2 is not None
+    u = helpers.hash_field(shape, np.float64, seed=8)
+    m = helpers.oracle.Module.parse(text)
+    o1, o2 = np.zeros(shape), np.zeros(shape)
+    m.call("step", o1, u)
+    m.call("step", o2, o1)
+    bounds = ([1, 1, 1], [n - 1 for n in shape])
+    fin = nh.fields.DeviceField.from_numpy(u)
+    out = nh.fields.DeviceField.empty_like(fin)
+    assert nh.apply.apply_twice(entry, fin, out, bounds)
+    nh.torch.cuda.synchronize()
+    assert helpers.bits_equal(out.numpy(), o2), helpers.mismatch_report(out.numpy(), o2)
+    # the operator itself (lap3d_0__geom2) and a 6-step loop of the Euler step
+    lap = mod.geom_entry("lap3d")
+    assert lap.fn2 is not None
+    a = nh.fields.DeviceField.from_numpy(u)
+    b = nh.fields.DeviceField.empty_like(a)
+    res = nh.apply.step_loop(entry, a, b, bounds, 6)
+    nh.torch.cuda.synchronize()
+    ha, hb = u.copy(), np.zeros(shape)
+    for _ in range(6):
+        m.call("step", hb, ha)
+        ha, hb = hb, ha
+    assert helpers.bits_equal(res.numpy(), ha), helpers.mismatch_report(res.numpy(), ha)

@@ -260,6 +260,61 @@ static void run_buf(const double* in, double* out, int N0, int N1, int N2, int c
   fflush(stdout);
 }
 
+// ragged rows, store side: the result rows start 8 bytes off a 16-byte boundary.  MODE 0: unaligned 16-byte stores (what
+// the march kernel did in round 1); MODE 1: results moved one cell across lanes (DPP) so that lanes 1..63 store ALIGNED
+// 16-byte vectors, lane 0 and lane 63 store the two 8-byte end pieces of the wave's span
+template <int MODE>
+__global__ __launch_bounds__(1024) void march_copy_ragged(P3 P) {
+  extern __shared__ char dyn_lds[];
+  constexpr int RJ = 4, WJ = 16;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = v % P.nK, t = v / P.nK, jt = t % P.nJ, ct = t / P.nJ;
+  const int32_t j0 = (int32_t)(jt * (WJ * RJ)) + w * RJ;
+  const int32_t k0 = (int32_t)(kt * 128u) + lane * 2;
+  const int32_t ib = (int32_t)ct * P.chunk;
+  const int32_t ie = ib + P.chunk < P.N0 ? ib + P.chunk : P.N0;
+  const int64_t plane = (int64_t)P.N1 * P.N2;
+  const int64_t base = (int64_t)j0 * P.N2 + k0;
+  V2 nxt[RJ];
+  sfor<RJ>([&](auto rc) { constexpr int r = rc; nxt[r] = *reinterpret_cast<const V2*>(P.in + (int64_t)ib * plane + base + (int64_t)r * P.N2); });
+  for (int32_t i = ib; i < ie; ++i) {
+    V2 cur[RJ];
+    sfor<RJ>([&](auto rc) { constexpr int r = rc; cur[r] = nxt[r]; });
+    __syncthreads();
+    if (i + 1 < ie)
+      sfor<RJ>([&](auto rc) { constexpr int r = rc; nxt[r] = *reinterpret_cast<const V2*>(P.in + (int64_t)(i + 1) * plane + base + (int64_t)r * P.N2); });
+    sfor<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      double* dst = P.out + (int64_t)i * plane + base + (int64_t)r * P.N2;   // 8 bytes off a 16-byte boundary
+      if constexpr (MODE == 0) {
+        typedef double UV2 __attribute__((ext_vector_type(2), aligned(8)));
+        __builtin_nontemporal_store(cur[r], reinterpret_cast<V2*>(dst));
+      } else {
+        // the aligned vector below my cells holds (previous lane's second cell, my first cell)
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(cur[r].y), 0x138, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(cur[r].y), 0x138, 0xf, 0xf, false);
+        V2 al = {__hiloint2double(hi, lo), cur[r].x};
+        if (lane > 0) __builtin_nontemporal_store(al, reinterpret_cast<V2*>(dst - 1));
+        else __builtin_nontemporal_store(cur[r].x, dst);
+        if (lane == 63) __builtin_nontemporal_store(cur[r].y, dst + 1);
+      }
+    });
+  }
+}
+template <int MODE>
+static void run_ragged(const char* what, const double* in, double* out, int N0, int N1, int N2, int reps) {
+  P3 P{in, out, N0, N1, N2, 128, (uint32_t)((N1 + 63) / 64), (uint32_t)((N2 + 127) / 128), (uint32_t)((N0 + 127) / 128), 0};
+  const uint32_t blocks = P.nJ * P.nK * P.nC;
+  const size_t lds = 159 * 1024;
+  auto kern = march_copy_ragged<MODE>;
+  CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const double ms = time_ms([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(1024), lds, 0, P); }, 2, reps);
+  printf("march_copy_ragged %-60s %8.4f ms %7.1f GB/s\n", what, ms, 2.0 * N0 * (double)N1 * N2 * 8 / ms / 1e6);
+  fflush(stdout);
+}
+
 // linear copies: U x 16 B per lane, exact grid
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void lin_copy(const V2* __restrict__ src, V2* __restrict__ dst, int64_t n16) {
@@ -462,6 +517,32 @@ int main(int argc, char** argv) {
     run_halo<7>("rows split + K-halo + J-halo rows (nt)", a, b, N0, N1, N2, 128, reps);
     run_halo<14>("rows nt + K-halo + J-halo rows (nt)", a, b, N0, N1, N2, 128, reps);
     run_halo<12>("rows nt + J-halo rows (nt)", a, b, N0, N1, N2, 128, reps);
+  }
+  // ragged rows: what 8-byte-misaligned 16-byte accesses cost on the load side and on the store side
+  // (same traversal; the field pointers are moved by one double, the last plane is left out to stay in bounds)
+  if (N0 > 2) {
+    run_march<4, 16, 1, 1, true, true, true>("aligned loads, aligned stores", a, b, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("MISALIGNED loads, aligned stores", a + 1, b, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("aligned loads, MISALIGNED stores", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("MISALIGNED loads and stores", a + 1, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, false>("aligned loads, MISALIGNED plain stores", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_ragged<0>("rows 8 B off: unaligned 16-byte stores", a, b + 1, N0 - 1, N1, N2, reps);
+    run_ragged<1>("rows 8 B off: results shifted one cell, aligned stores + 8-byte ends", a, b + 1, N0 - 1, N1, N2, reps);
+    run_ragged<0>("rows aligned: plain 16-byte stores (reference)", a, b, N0 - 1, N1, N2, reps);
+    // which granule has to be written whole?  stores whose wave spans start 16 / 32 / 64 bytes off a 128-byte line
+    run_march<4, 16, 1, 1, true, true, true>("stores +16 B", a, b + 2, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("stores +32 B", a, b + 4, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("stores +64 B", a, b + 8, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 16, 1, 1, true, true, true>("stores +0 B", a, b, N0 - 1, N1, N2, 128, reps, 0, 1);
+    // do the halves of a sector that two waves of ONE workgroup write at the same time merge in L2?
+    run_march<4, 8, 2, 1, true, true, true>("wk2 aligned", a, b, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 8, 2, 1, true, true, true>("wk2 MISALIGNED stores nt", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 8, 2, 1, true, true, false>("wk2 MISALIGNED stores plain", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 2, 8, 1, true, true, true>("wk8 aligned", a, b, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 2, 8, 1, true, true, true>("wk8 MISALIGNED stores nt", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 2, 8, 1, true, true, false>("wk8 MISALIGNED stores plain", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 4, 4, 1, true, true, true>("wk4 MISALIGNED stores nt", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
+    run_march<4, 4, 4, 1, true, true, false>("wk4 MISALIGNED stores plain", a, b + 1, N0 - 1, N1, N2, 128, reps, 0, 1);
   }
   CHECK(hipFree(a));
   CHECK(hipFree(b));

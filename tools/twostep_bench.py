@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Steps per second of an explicit time loop with one apply per pass over HBM and with two
+(neptune_hip_step_loop_pairs / csrc/kernels/apply_march2.hpp): the built-in 7-point operator and a lowered module's
+fused Euler step u + dt * lap(u).   usage: tools/twostep_bench.py [N ...]   (default 1024 512)"""
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
+sys.path.insert(0, str(REPO / "tools"))
+
+
+def main():
+    import torch
+    import make_stencil_mlir
+    from neptune_hip import _capi, apply, fields, lowering
+    lib = _capi.load()
+    lib.neptune_hip_init(0)
+    sizes = [int(x) for x in sys.argv[1:]] or [1024, 512]
+    for n in sizes:
+        shape = (n, n, n)
+        steps = 40 if n >= 1024 else 200
+        bounds = ([1, 1, 1], [n - 1] * 3)
+        mod = lowering.compile_module(make_stencil_mlir.stencil_module("3d7", list(shape), time_step=1e-3))
+        for name, body in (("built-in 7-point operator", _capi.BODY_LAP3D7_F64), ("lowered @lap3d", mod.geom_entry("lap3d")),
+                           ("lowered fused Euler @step", mod.geom_entry("step"))):
+            a = fields.DeviceField.hashed(shape, _capi.F64, seed=5)
+            a.tensor.mul_(1e-3)
+            b = fields.DeviceField.empty_like(a)
+            row = {"field": f"{n}^3 f64", "body": name, "steps": steps}
+            for label, env in (("one_apply_per_pass", "1"), ("two_applies_per_pass", "")):
+                if env:
+                    os.environ["NEPTUNE_HIP_NO_PAIRS"] = env
+                else:
+                    os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
+                apply.step_loop(body, a, b, bounds, 8)           # warm: graph capture, clocks
+                a.fill_hash(5)
+                a.tensor.mul_(1e-3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                apply.step_loop(body, a, b, bounds, steps)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t0) * 1e3 / steps
+                row[label + "_ms_per_step"] = round(ms, 4)
+                row[label + "_GBps_algorithmic"] = round(2 * n ** 3 * 8 / ms / 1e6, 1)
+            row["speedup"] = round(row["one_apply_per_pass_ms_per_step"] / row["two_applies_per_pass_ms_per_step"], 3)
+            print(json.dumps(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()
