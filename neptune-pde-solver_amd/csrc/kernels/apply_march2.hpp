@@ -18,9 +18,10 @@
 //   * stage 1 computes v on the whole window from u (K neighbours by wave shifts, J neighbours of the window's own
 //     rows through LDS); v is therefore valid one cell / one row inside the window's edge, and stage 2's result w two
 //     cells / rows inside.  Windows OVERLAP instead of fetching halos: the row stride between workgroups is TJ - 4 and
-//     the column stride 64*VK - 64 B/sizeof(T) -- the kept columns start 4 lane vectors... [kw + KEEP0, ...) is a whole
-//     number of 64-byte granules, so every store instruction writes whole granules (a partially written granule costs
-//     a read-modify-write at the memory side: profiles/r02_headline_search.txt section 3).  No scalar halo loads at all.
+//     the column stride one 64-byte granule less than the wave span (120 of 128 fp64 cells), with the kept columns
+//     starting half a granule inside the window: every store instruction then writes whole 64-byte granules (a
+//     partially written granule costs a read-modify-write at the memory side: profiles/r02_ragged_probe.txt).  No scalar
+//     halo loads at all, no workgroup-edge row loads.
 //   * along dim 0 the wave keeps 3 planes of u and 3 planes of v in registers; step i loads u(i+3), computes v(i+1)
 //     from u(i..i+2) and w(i) from v(i-1..i+1), stores w(i).  A chunk starts two planes early (results discarded)
 //     to fill the v ring: 4 redundant plane reads per chunk.
@@ -42,9 +43,9 @@ struct March2Params {
   uint32_t nJ, nK;
 };
 
-// RJ rows per lane, WJ waves per workgroup
-template <class Body, class T, class FP, int RJ, int WJ>
-__global__ __launch_bounds__(kWave* WJ) void neptune_apply_march2(March2Params<T> P, Body body) {
+// RJ rows per lane, WJ waves per workgroup, MINW = waves per SIMD the register allocation must leave room for
+template <class Body, class T, class FP, int RJ, int WJ, int MINW>
+__global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Params<T> P, Body body) {
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
   constexpr int TJ = RJ * WJ;                 // window rows
@@ -203,11 +204,9 @@ inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* in, c
   return true;
 }
 
-template <class Body, class T, class FP, int RJ = 4, int WJ = 8>
-inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
-                         int chunk_req) {
-  if (!march2_eligible<T, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
-  if (geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;   // pure copies: leave to the plain path
+template <class Body, class T, class FP, int RJ, int WJ, int MINW>
+inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+                               int chunk_req) {
   constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T);
   constexpr int KEEPJ = RJ * WJ - 4, KEEPK = kWave * VK - G;
   March2Params<T> P{};
@@ -229,19 +228,38 @@ inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, co
   const int64_t planes = P.rI1 - P.rI0;
   int64_t chunk = chunk_req > 0 ? chunk_req : 128;
   // small fields: enough workgroups for every CU
-  while (chunk > 16 && (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk) < 512) chunk /= 2;
+  while (chunk_req <= 0 && chunk > 16 && (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk) < 512) chunk /= 2;
   if (chunk > planes) chunk = planes;
   P.chunk = (int32_t)chunk;
   const int64_t blocks = (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk);
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
-  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, RJ, WJ>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P, body);
+  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, RJ, WJ, MINW>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P, body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;
 }
 
-// what callers use: two chained applies of `body` if the footprint and the geometry allow it, else
-// NEPTUNE_HIP_EUNSUPPORTED (the caller then launches the apply twice); never instantiates the kernel for a footprint it
-// cannot serve
+template <class Body, class T, class FP>
+inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+                         int chunk_req) {
+  if (!march2_eligible<T, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
+  if (geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;   // pure copies: leave to the plain path
+  // window shape: NEPTUNE_HIP_MARCH2 = 0..4 picks one for measurements (tools/twostep_bench.py)
+  static const int shape = [] { const char* e = getenv("NEPTUNE_HIP_MARCH2"); return e ? atoi(e) : 0; }();
+  // Measured on 1024^3 fp64, 7-point operator, 128-plane chunks, steps/s against one apply per pass (2.82 ms/step),
+  // profiles/r02_twostep.txt:  rows per lane x waves  3x16: 1.79x (108 VGPRs)   7x8: 1.81x (228 VGPRs)   6x8: 1.75x
+  // 2x16: 1.74x   5x8: 1.75x   4x8: 1.59x   4x16 (spills): 1.51x.  Default: 3x16 -- sixteen waves keep 48 KiB of row loads
+  // in flight per CU with registers to spare for bodies heavier than the Laplacian.
+  switch (shape) {
+    default:
+    case 0: return launch_march2_shape<Body, T, FP, 3, 16, 1>(body, g, in, out, stream, chunk_req);
+#if NEPTUNE_HIP_FULL_VARIANTS
+    case 1: return launch_march2_shape<Body, T, FP, 7, 8, 1>(body, g, in, out, stream, chunk_req);
+    case 2: return launch_march2_shape<Body, T, FP, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+    case 3: return launch_march2_shape<Body, T, FP, 2, 16, 1>(body, g, in, out, stream, chunk_req);
+#endif
+  }
+}
+
 template <class Body, class T, int RANK, int NIN, class FP>
 inline int launch_apply_twice(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                               hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {

@@ -25,15 +25,36 @@ def nh():
     return ns
 
 
-# shapes: window seams along every axis (rows 28 per workgroup, columns 120 per wave, chunk seams), first / last
-# tiles partially outside the field, a shifted logical origin and bounds tighter than the interior
+# shapes: window seams along every axis (44 rows per workgroup of the default 3 x 16 window, 52 / 28 / 28 of the others;
+# 120 columns per wave; chunk seams), first / last tiles partially outside the field, a shifted logical origin and bounds
+# tighter than the interior
 CASES = [
     ((9, 40, 256), None, None),
+    ((7, 100, 256), None, None),
     ((34, 61, 376), None, None),
     ((20, 29, 128), None, None),                       # one wave span, rows just over one workgroup window
     ((12, 30, 256), [5, -3, 7], None),                 # shifted origin (index arguments are not used by this body, boxes are)
     ((16, 40, 256), None, ([2, 3, 9], [13, 33, 201])),  # bounds tighter than the interior: copy-through bands inside
 ]
+
+
+@pytest.fixture(params=["0", "1", "2", "3"], ids=["rows3x16", "rows7x8", "rows4x8", "rows2x16"])
+def window(request, monkeypatch):
+    """every window shape the library holds (NEPTUNE_HIP_MARCH2 is read once per process, at the first pair launch:
+    the other shapes are reached through a child process)"""
+    return request.param
+
+
+def test_every_window_shape_in_a_child_process(window, built_libs):
+    import os
+    import subprocess
+    import sys
+    if window == "0":
+        pytest.skip("the default window is what every other test of this file runs")
+    env = dict(os.environ, NEPTUNE_HIP_MARCH2=window)
+    p = subprocess.run([sys.executable, "-m", "pytest", __file__, "-x", "-q", "-m", "gpu", "-k", "one_pass_equal or step_loop_uses_pairs",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 
 
 @pytest.mark.parametrize("shape,origin,bounds", CASES)

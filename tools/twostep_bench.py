@@ -19,29 +19,33 @@ def main():
     from neptune_hip import _capi, apply, fields, lowering
     lib = _capi.load()
     lib.neptune_hip_init(0)
-    sizes = [int(x) for x in sys.argv[1:]] or [1024, 512]
+    sizes = [int(x) for x in sys.argv[1:] if x.isdigit()] or [1024, 512]
+    only_builtin = "--builtin-only" in sys.argv
     for n in sizes:
         shape = (n, n, n)
         steps = 40 if n >= 1024 else 200
         bounds = ([1, 1, 1], [n - 1] * 3)
-        mod = lowering.compile_module(make_stencil_mlir.stencil_module("3d7", list(shape), time_step=1e-3))
-        for name, body in (("built-in 7-point operator", _capi.BODY_LAP3D7_F64), ("lowered @lap3d", mod.geom_entry("lap3d")),
-                           ("lowered fused Euler @step", mod.geom_entry("step"))):
+        cases = [("built-in 7-point operator", _capi.BODY_LAP3D7_F64)]
+        if not only_builtin:
+            mod = lowering.compile_module(make_stencil_mlir.stencil_module("3d7", list(shape), time_step=1e-3))
+            cases += [("lowered @lap3d", mod.geom_entry("lap3d")), ("lowered fused Euler @step", mod.geom_entry("step"))]
+        chunk = int(os.environ.get("TWOSTEP_CHUNK", "0"))
+        for name, body in cases:
             a = fields.DeviceField.hashed(shape, _capi.F64, seed=5)
             a.tensor.mul_(1e-3)
             b = fields.DeviceField.empty_like(a)
-            row = {"field": f"{n}^3 f64", "body": name, "steps": steps}
+            row = {"field": f"{n}^3 f64", "body": name, "steps": steps, "shape_variant": os.environ.get("NEPTUNE_HIP_MARCH2", "0"), "chunk": chunk}
             for label, env in (("one_apply_per_pass", "1"), ("two_applies_per_pass", "")):
                 if env:
                     os.environ["NEPTUNE_HIP_NO_PAIRS"] = env
                 else:
                     os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
-                apply.step_loop(body, a, b, bounds, 8)           # warm: graph capture, clocks
+                apply.step_loop(body, a, b, bounds, 8, cfg=apply.make_cfg(chunk=chunk) if chunk and not env else None)   # warm: graph capture, clocks
                 a.fill_hash(5)
                 a.tensor.mul_(1e-3)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                apply.step_loop(body, a, b, bounds, steps)
+                apply.step_loop(body, a, b, bounds, steps, cfg=apply.make_cfg(chunk=chunk) if chunk and not env else None)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) * 1e3 / steps
                 row[label + "_ms_per_step"] = round(ms, 4)
