@@ -13,17 +13,25 @@ import re
 
 
 def short(name):
-    """kernel name without the boilerplate; march kernels keep their tile (one template instantiation per tile
-    variant: RJ, WJ, WK, dpp, nt-store, PF, nt-load, lds-J, tile-form, late-J-halo)"""
+    """kernel name without the boilerplate; march kernels get the library's own tile name (template arguments of
+    Tile<RJ, WJ, WK, dpp, nt-store, PF, nt-load, lds-J, tile-form, late-J-halo, K-halo lead>)"""
     m = re.search(r"neptune_apply_march<.*?Tile<([^>]*)>", name)
     if m:
         a = [x.strip() for x in m.group(1).split(",")]
-        f = lambda i: a[i] == "true"
-        tag = f"rj{a[0]}_wj{a[1]}_wk{a[2]}_pf{a[5]}" + ("_lds" if f(7) else "") + ("_jhl" if f(9) else "") + \
-              ("_tile" if f(8) else "") + ("" if f(3) else "_shfl") + ("" if f(4) else "_plainst")
+        f = lambda i: i < len(a) and a[i] == "true"
+        kd = a[10] if len(a) > 10 else "1"
+        if f(8):
+            tag = f"tile_rj{a[0]}_wj{a[1]}_wk{a[2]}"
+        else:
+            tag = f"rj{a[0]}_wj{a[1]}_wk{a[2]}_pf{a[5]}" + ("_lds" if f(7) else "") + ("_jhl" if f(9) else "") + \
+                  (f"_kd{kd}" if kd != "1" else "") + ("_ntl" if f(6) else "")
+        tag += ("" if f(3) else "_shfl") + ("" if f(4) else "_plainst")
         return "neptune_apply_march[" + tag + "]"
+    m = re.search(r"neptune_apply_march2<.*?, (\d+), (\d+), \d+>", name)
+    if m:
+        return f"neptune_apply_march2[rows{m.group(1)}x{m.group(2)}]"
     for key in ("neptune_apply_direct", "neptune_apply_rows", "neptune_reduce_apply_vec", "neptune_reduce_apply", "neptune_fill_hash",
-                "neptune_copy16", "neptune_store_box"):
+                "neptune_copy16", "neptune_store_box", "neptune_vec_update"):
         if key in name:
             return key
     return name[:60]

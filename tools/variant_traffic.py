@@ -19,6 +19,7 @@ REPO = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
 sys.path.insert(0, str(REPO))
 REPS = 2
+ROUND = os.environ.get("NEPTUNE_PROFILE_ROUND", "r02")
 
 
 def run(workload):
@@ -80,15 +81,14 @@ def parse(workload, fetch_dir, write_dir, update=None):
         entries[f"{workload}|neptune_apply_march|{name}"] = {
             "fetch_size_kib_per_launch": f, "write_size_kib_per_launch": w, "traffic_bytes_per_launch": t,
             "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": t / alg,
-            "source": f"profiles/r01_variant_traffic_{workload}.txt"}
+            "source": f"profiles/{ROUND}_variant_traffic_{workload}.txt"}
     if update:
         p = Path(update)
         doc = json.loads(p.read_text())
-        for k, e in entries.items():
-            old = doc["entries"].get(k)
-            if old and "kernel_avg_ns_under_rocprof" in old:
-                continue                      # keep the entries that come with a full bench profile
-            doc["entries"][k] = e
+        # every entry of this workload is replaced: an entry's `source` must hold exactly the number it quotes
+        for k in [k for k in doc["entries"] if k.startswith(workload + "|")]:
+            del doc["entries"][k]
+        doc["entries"].update(entries)
         p.write_text(json.dumps(doc, indent=1) + "\n")
 
 

@@ -8,7 +8,7 @@ for W in "$@"; do
   mkdir -p "$OUT"
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$ROOT/tools/variant_traffic.py" run "$W" > "$OUT/fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$ROOT/tools/variant_traffic.py" run "$W" > "$OUT/write.log" 2>&1
-  python3 "$ROOT/tools/variant_traffic.py" parse "$W" "$OUT/fetch" "$OUT/write" | tee "$ROOT/gpurun_out/vt_$W.txt"
+  python3 "$ROOT/tools/variant_traffic.py" parse "$W" "$OUT/fetch" "$OUT/write" ${UPDATE:+--update "$UPDATE"} | tee "$ROOT/gpurun_out/vt_$W.txt"
   # keep only the counter tables (the raw dirs also hold large agent-info files)
   find "$OUT" -name "*agent_info*" -delete
 done
