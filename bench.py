@@ -472,6 +472,11 @@ def main():
     lib.neptune_hip_event_destroy(ev1)
     if world > 1:
         dist.barrier()
+    del op, sharded                      # the C-side plan (its stream and events) before its communicator
+    if rccl_comm is not None:
+        torch.cuda.synchronize()
+        rccl_comm.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

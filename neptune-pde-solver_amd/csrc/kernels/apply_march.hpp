@@ -239,10 +239,19 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // ... and the exchange buffers (2 x halo inputs x waves x 2*R1 rows x 1 KiB) must leave room for a second
   // workgroup per CU (160 KiB LDS): beyond 64 KiB -- three halo inputs of radius 2 on an 8-wave tile -- the
   // halo rows come from global memory like in the tiles without LDSJ
-  constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && R1 <= RJ && HAS_HALO &&
-                        2 * NHX * WJ * WK * 2 * R1 * kWave * (int)sizeof(V) <= 64 * 1024;
-  constexpr int LROWS = LDSJ ? 2 * R1 : 1;
-  // [double buffer][halo input][wave][first R1 own rows | last R1 own rows][lane]: 1 KiB per row
+  // A J radius larger than the rows per lane (radius 3-4 stars on the 2-row tiles) reaches past the adjacent wave: every wave
+  // then publishes ALL its own rows and takes halo row x from the wave ceil(distance / RJ) away (LDS_ALL); rows beyond
+  // the workgroup's window still come from global memory, loaded by the waves close enough to the window's edge.
+  constexpr bool LDS_ALL = R1 > RJ;
+  constexpr int LPUB = LDS_ALL ? RJ : 2 * R1;   // rows a wave publishes per halo input and step
+  constexpr bool LDSJ = TL::LDSJ && WJ > 1 && R1 > 0 && HAS_HALO &&
+                        2 * NHX * WJ * WK * LPUB * kWave * (int)sizeof(V) <= 64 * 1024;
+  constexpr int LROWS = LDSJ ? LPUB : 1;
+  // how many waves away halo row x lives (x < R1: rows above the tile, nearest last; x >= R1: rows below, nearest first)
+  // and which of that wave's own rows it is
+  auto halo_dist = [](int x) constexpr { return x < R1 ? (R1 - x + RJ - 1) / RJ : (x - R1) / RJ + 1; };
+  auto halo_row = [](int x) constexpr { return x < R1 ? RJ * ((R1 - x + RJ - 1) / RJ) - (R1 - x) : (x - R1) % RJ; };
+  // [double buffer][halo input][wave][published rows][lane]: 1 KiB per row.  Adjacent-wave form: first R1 own rows | last R1
   __shared__ V lds_rows[LDSJ ? 2 : 1][LDSJ ? NHX : 1][LDSJ ? WJ * WK : 1][LROWS][LDSJ ? kWave : 1];
 
   const int lane = threadIdx.x & (kWave - 1);
@@ -325,13 +334,13 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
           if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
           else rows[s] = *src;
         };
-        constexpr bool halo_row = s < R1 || s >= R1 + RJ;
-        if constexpr (JH_LATE && halo_row) {
+        constexpr bool is_halo_row = s < R1 || s >= R1 + RJ;
+        if constexpr (JH_LATE && is_halo_row) {
           // star: halo rows are fetched by load_jhalo when the plane becomes the centre
         } else if constexpr (LDSJ && !all_rows && s < R1) {
-          if (wj == 0) ld();           // top rows of the workgroup: no wave above to get them from
+          if (wj < halo_dist(s)) ld();            // above the workgroup's window: no wave to get them from
         } else if constexpr (LDSJ && !all_rows && s >= R1 + RJ) {
-          if (wj == WJ - 1) ld();      // bottom rows of the workgroup
+          if (wj + halo_dist(s - RJ) > WJ - 1) ld();   // below the window (halo index of slot s: s - RJ)
         } else {
           ld();
         }
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
       static_for<2 * R1>([&](auto xc) {
         constexpr int x = xc;
         constexpr int s = x < R1 ? x : RJ + x;  // ring slot of that row (R1 + RJ + (x - R1))
-        const bool want = !LDSJ || (x < R1 ? wj == 0 : wj == WJ - 1);
+        const bool want = !LDSJ || (x < R1 ? wj < halo_dist(x) : wj + halo_dist(x) > WJ - 1);
         if (want) {
           const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
           if constexpr (NTL) jh[x] = __builtin_nontemporal_load(src);
@@ -464,21 +473,35 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
       const int buf = (i - ib) & 1;
       static_for<NH>([&](auto hc) {
         constexpr int h = hc;
-        static_for<R1>([&](auto xc) {
-          constexpr int x = xc;
-          lds_rows[buf][h][w][x][lane] = ring[h][PJ][R1 + x];            // first own rows
-          lds_rows[buf][h][w][R1 + x][lane] = ring[h][PJ][RJ + x];       // last own rows (s = R1+RJ-R1+x)
-        });
+        if constexpr (LDS_ALL) {
+          static_for<RJ>([&](auto rc) { constexpr int r = rc; lds_rows[buf][h][w][r][lane] = ring[h][PJ][R1 + r]; });
+        } else {
+          static_for<R1>([&](auto xc) {
+            constexpr int x = xc;
+            lds_rows[buf][h][w][x][lane] = ring[h][PJ][R1 + x];            // first own rows
+            lds_rows[buf][h][w][R1 + x][lane] = ring[h][PJ][RJ + x];       // last own rows (s = R1+RJ-R1+x)
+          });
+        }
       });
       __syncthreads();
       static_for<NH>([&](auto hc) {
         constexpr int h = hc;
-        static_for<R1>([&](auto xc) {
-          constexpr int x = xc;
-          // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
-          if (wj > 0) ring[h][PJ][x] = lds_rows[buf][h][w - WK][R1 + x][lane];
-          if (wj < WJ - 1) ring[h][PJ][R1 + RJ + x] = lds_rows[buf][h][w + WK][x][lane];
-        });
+        if constexpr (LDS_ALL) {
+          static_for<2 * R1>([&](auto xc) {
+            constexpr int x = xc;                       // halo index: x < R1 above, else below
+            constexpr int d = halo_dist(x), r = halo_row(x);
+            constexpr int s = x < R1 ? x : RJ + x;      // ring slot of that row
+            if constexpr (x < R1) { if (wj >= d) ring[h][PJ][s] = lds_rows[buf][h][w - d * WK][r][lane]; }
+            else { if (wj + d <= WJ - 1) ring[h][PJ][s] = lds_rows[buf][h][w + d * WK][r][lane]; }
+          });
+        } else {
+          static_for<R1>([&](auto xc) {
+            constexpr int x = xc;
+            // rows above my tile = last rows of the wave above; rows below = first rows of the wave below
+            if (wj > 0) ring[h][PJ][x] = lds_rows[buf][h][w - WK][R1 + x][lane];
+            if (wj < WJ - 1) ring[h][PJ][R1 + RJ + x] = lds_rows[buf][h][w + WK][x][lane];
+          });
+        }
       });
     }
     static_for<NIN>([&](auto nc) {
