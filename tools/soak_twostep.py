@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Soak for the two-applies-per-pass kernel (csrc/kernels/apply_march2.hpp): random shapes (rows of whole 64-byte
+granules), logical origins, apply bounds, plane-range launch regions and chunk lengths; out = A(A(in)) in one launch must
+equal two launches of the march kernel AND the oracle's chained applies, bit for bit.  The window shape is chosen with
+NEPTUNE_HIP_MARCH2 (read once per process): run once per shape.   usage: tools/soak_twostep.py [cases] [seed]"""
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
+sys.path.insert(0, str(REPO / "tests"))
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    import helpers
+    from neptune_hip import _capi, apply, fields
+    lib = _capi.load()
+    lib.neptune_hip_init(0)
+    rng = np.random.default_rng(seed)
+    body = _capi.BODY_LAP3D7_F64
+    t0 = time.time()
+    launches = refused = 0
+    for c in range(cases):
+        shape = [int(rng.integers(1, 40)), int(rng.integers(8, 120)), int(rng.choice([16, 64, 120, 128, 136, 248, 256, 376, 512]))]
+        origin = [int(rng.integers(-9, 10)) for _ in range(3)]
+        lb, ub = [], []
+        for d in range(3):
+            lo = int(rng.integers(1, max(2, shape[d] // 2)))
+            hi = int(rng.integers(lo, shape[d])) if lo < shape[d] else lo
+            lb.append(origin[d] + lo)
+            ub.append(origin[d] + max(min(hi, shape[d] - 1), lo))
+        u = helpers.hash_field(tuple(shape), np.float64, seed=int(rng.integers(1, 1 << 30)))
+        fin = fields.DeviceField.from_numpy(u, origin)
+        mid, two, one = (fields.DeviceField.empty_like(fin) for _ in range(3))
+        regions = [None]
+        if shape[0] > 4:
+            a = int(rng.integers(0, shape[0] - 1))
+            b = int(rng.integers(a + 1, shape[0] + 1))
+            regions.append(([a, 0, 0], [b, shape[1], shape[2]]))
+        empty = any(l >= h for l, h in zip(lb, ub))
+        o = None
+        for region in regions:
+            # reference: two launches; the second one's region is the same plane range, the first covers the whole field
+            apply.apply_builtin(body, [fin], mid, (lb, ub))
+            two.tensor.fill_(float("nan"))
+            apply.apply_builtin(body, [mid], two, (lb, ub), region=region)
+            for chunk in (0, 1, 3, int(rng.integers(2, 40))):
+                one.tensor.fill_(float("nan"))
+                ok = apply.apply_twice(body, fin, one, (lb, ub), region=region, cfg=apply.make_cfg(chunk=chunk))
+                if not ok:
+                    refused += 1
+                    assert empty, f"case {c}: refused a geometry that qualifies: shape {shape} bounds {lb} {ub}"
+                    break
+                launches += 1
+                torch.cuda.synchronize()
+                got, want = one.numpy(), two.numpy()
+                if not helpers.bits_equal(got, want):
+                    print(f"MISMATCH case {c} shape {shape} origin {origin} bounds {lb} {ub} region {region} chunk {chunk}\n"
+                          + helpers.mismatch_report(got, want))
+                    sys.exit(1)
+            if region is None and not empty:
+                o = helpers.oracle_entry("3d7", helpers.oracle_entry("3d7", u, origin, (lb, ub)), origin, (lb, ub))
+                assert helpers.bits_equal(two.numpy(), o), f"case {c}: two launches differ from the oracle"
+    print(f"SOAK_TWOSTEP_OK window={os.environ.get('NEPTUNE_HIP_MARCH2', '0')} cases={cases} seed={seed} pair_launches={launches} "
+          f"refused_empty={refused} seconds={time.time() - t0:.0f}")
+
+
+if __name__ == "__main__":
+    main()
