@@ -232,17 +232,24 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
                           void *const fields[2], const void *const *in, int64_t steps, void *stream,
                           const neptune_hip_launch_cfg_t *cfg);
 
-/* Two steps per pass over HBM.  neptune_hip_apply2_builtin computes out = A(A(in)) for built-in body A in ONE launch
- * (the intermediate field exists in registers only; same operations on the same operands as two launches, hence the
- * same bits) when the body is a rank-3 single-input radius-1 star and the geometry qualifies (all boxes equal, rows a
- * whole number of 64-byte granules, launch region restricted along dim 0 only); otherwise NEPTUNE_HIP_EUNSUPPORTED and
- * nothing is launched.  Lowered applies export the same thing as <function>_<k>__geom2.
- * neptune_hip_step_loop uses it for the built-in bodies on its own; neptune_hip_step_loop_pairs is the same loop with a
- * lowered apply's pair entry `fn2` (NULL = none) next to its single-step entry `fn`.  The reference steps one apply per
- * pass on the host (runtime forward Euler, NeptunePETScRuntime.cpp:677-712). */
+/* Several steps per pass over HBM.  neptune_hip_apply_chain_builtin computes out = A(A(in)) (applies = 2) or A(A(A(in)))
+ * (applies = 3) for built-in body A in ONE launch -- the intermediate fields exist in registers only; the same operations on
+ * the same operands as separate launches, hence the same bits -- when the body is a rank-3 single-input radius-1 star and the
+ * geometry qualifies (all boxes equal, rows a whole number of 64-byte granules, launch region restricted along dim 0 only);
+ * otherwise NEPTUNE_HIP_EUNSUPPORTED and nothing is launched.  neptune_hip_apply2_builtin is the applies = 2 form.  Lowered
+ * applies export the same as <function>_<k>__geom2 / __geom3.
+ * neptune_hip_step_loop uses them for the built-in bodies on its own; neptune_hip_step_loop_chain is the same loop with a
+ * lowered apply's pair / triple entries `fn2`, `fn3` (NULL = none) next to its single-step entry `fn`
+ * (neptune_hip_step_loop_pairs: fn3 = NULL).  The newest state ends in fields[steps % 2] whatever the grouping.  The
+ * reference steps one apply per pass on the host (runtime forward Euler, NeptunePETScRuntime.cpp:677-712). */
+int neptune_hip_apply_chain_builtin(int body, int applies, const neptune_hip_apply_geom_t *g, const void *const *in,
+                                    void *out, void *stream, const neptune_hip_launch_cfg_t *cfg);
 int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t *g, const void *const *in, void *out,
                                void *stream, const neptune_hip_launch_cfg_t *cfg);
 int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, int body,
+                                const neptune_hip_apply_geom_t *g, void *const fields[2], const void *const *in,
+                                int64_t steps, void *stream, const neptune_hip_launch_cfg_t *cfg);
+int neptune_hip_step_loop_chain(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, neptune_hip_apply_fn fn3, int body,
                                 const neptune_hip_apply_geom_t *g, void *const fields[2], const void *const *in,
                                 int64_t steps, void *stream, const neptune_hip_launch_cfg_t *cfg);
 

@@ -43,19 +43,23 @@ struct March2Params {
   uint32_t nJ, nK;
 };
 
-// RJ rows per lane, WJ waves per workgroup, MINW = waves per SIMD the register allocation must leave room for
-template <class Body, class T, class FP, int RJ, int WJ, int MINW>
+// NS chained applies per pass (2 or 3); RJ rows per lane, WJ waves per workgroup, MINW = waves per SIMD the register
+// allocation must leave room for.  Stage k = 1..NS computes v_k = A(v_{k-1}) (v_0 = the input u, v_NS = the result w);
+// at step i stage k produces plane i + NS - k, so each stage's newest plane is the next stage's upper neighbour plane
+// within the same step.  v_k is valid k cells / rows inside the window.
+template <class Body, class T, class FP, int NS, int RJ, int WJ, int MINW>
 __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Params<T> P, Body body) {
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
+  static_assert(NS >= 2 && NS <= 3, "two or three applies per pass");
   constexpr int TJ = RJ * WJ;                 // window rows
-  constexpr int KEEPJ = TJ - 4;               // rows of w this workgroup stores: [Jb + 2, Jb + TJ - 2)
+  constexpr int KEEPJ = TJ - 2 * NS;          // rows of w this workgroup stores: [Jb + NS, Jb + TJ - NS)
   constexpr int G = 64 / (int)sizeof(T);      // cells per 64-byte store granule
   constexpr int SPAN = kWave * VK;            // window columns
   constexpr int KEEPK = SPAN - G;             // columns of w this wave stores: [kw + G/2, kw + SPAN - G/2)
-  static_assert((G / 2) % VK == 0 && G / 2 >= 2, "the kept columns must start at a whole lane, two cells inside");
+  static_assert((G / 2) % VK == 0 && G / 2 >= NS, "the kept columns must start at a whole lane, NS cells inside");
   static_assert(FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u, "radius-1 star of input 0");
-  __shared__ V lds[2][WJ][4][kWave];          // [parity][wave][u first, u last, v first, v last][lane]
+  __shared__ V lds[2][WJ][2 * NS][kWave];     // [parity][wave][stage input k: first own row, last own row][lane]
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   const uint32_t jt = t % P.nJ;
   const uint32_t ct = t / P.nJ;
 
-  const int32_t Jb = (int32_t)(jt * KEEPJ) - 2;          // first row of the window
+  const int32_t Jb = (int32_t)(jt * KEEPJ) - NS;         // first row of the window
   const int32_t j0 = Jb + w * RJ;                        // first own row
   const int32_t kw = (int32_t)(kt * KEEPK) - G / 2;      // first column of the window
   const int32_t k0 = kw + lane * VK;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   static_for<RJ>([&](auto rc) {
     constexpr int r = rc;
     const int32_t j = j0 + r;
-    row_keep[r] = j >= Jb + 2 && j < Jb + TJ - 2 && j >= 0 && j < P.N1;
+    row_keep[r] = j >= Jb + NS && j < Jb + TJ - NS && j >= 0 && j < P.N1;
     in_j[r] = j >= P.plb[1] && j < P.pub[1];
   });
   static_for<VK>([&](auto ec) {
@@ -142,31 +146,45 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
     });
   };
 
-  // ---- register state: planes are named by their distance from the step's plane i
-  V u0[RJ], u1[RJ], u2[RJ], un[RJ];   // u(i), u(i+1), u(i+2), u(i+3) in flight
-  V vm[RJ], v0[RJ], v1[RJ];           // v(i-1), v(i), v(i+1)
+  // ---- register state.  ring[k] holds the three newest planes of v_k that stage k+1 reads: at step i these are planes
+  // i+NS-k-2, i+NS-k-1 (the centre of stage k+1), i+NS-k; ring[k][2] is written by stage k in the same step (k = 0: by
+  // the load issued one step earlier).
+  V ring[NS][3][RJ];
+  V un[RJ];                                // u(i + NS + 1) in flight
   V wres[RJ];
-  const int32_t i0 = ib - 2;          // two warm-up steps fill the v ring (their w is discarded)
-  load_plane(i0, u0);
-  load_plane(i0 + 1, u1);
-  load_plane(i0 + 2, un);
-  static_for<RJ>([&](auto rc) { constexpr int r = rc; vm[r] = u0[r]; v0[r] = u0[r]; });   // defined, never kept
+  const int32_t i0 = ib - 2 * (NS - 1);    // warm-up steps fill the rings of the intermediate fields (their w is discarded)
+  load_plane(i0 + NS - 2, ring[0][0]);
+  load_plane(i0 + NS - 1, ring[0][1]);
+  load_plane(i0 + NS, un);
+  static_for<NS - 1>([&](auto kc) {        // defined, never part of a kept result
+    constexpr int k = kc + 1;
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][0][r] = ring[0][0][r]; ring[k][1][r] = ring[0][0][r]; });
+  });
 
   for (int32_t i = i0; i < ie; ++i) {
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; u2[r] = un[r]; });
-    // J-halo rows of u(i+1) and of v(i): publish my first / last own rows, take the neighbouring waves'
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[0][2][r] = un[r]; });
+    // J-halo rows of every stage's centre plane: publish my first / last own rows, take the neighbouring waves'
     const int buf = (i - i0) & 1;
-    lds[buf][w][0][lane] = u1[0];
-    lds[buf][w][1][lane] = u1[RJ - 1];
-    lds[buf][w][2][lane] = v0[0];
-    lds[buf][w][3][lane] = v0[RJ - 1];
+    static_for<NS>([&](auto kc) {
+      constexpr int k = kc;
+      lds[buf][w][2 * k][lane] = ring[k][1][0];
+      lds[buf][w][2 * k + 1][lane] = ring[k][1][RJ - 1];
+    });
     __syncthreads();
-    V ua = u1[0], ubl = u1[RJ - 1], va = v0[0], vbl = v0[RJ - 1];   // window-edge waves: any value (rows not kept)
-    if (w > 0) { ua = lds[buf][w - 1][1][lane]; va = lds[buf][w - 1][3][lane]; }
-    if (w < WJ - 1) { ubl = lds[buf][w + 1][0][lane]; vbl = lds[buf][w + 1][2][lane]; }
-    if (i + 3 <= ie + 1) load_plane(i + 3, un);   // u(ie+1) is the last plane any kept result depends on
-    stage(u0, u1, u2, ua, ubl, i + 1, v1);        // v(i+1)
-    stage(vm, v0, v1, va, vbl, i, wres);          // w(i)
+    V above[NS], below[NS];
+    static_for<NS>([&](auto kc) {
+      constexpr int k = kc;
+      above[k] = ring[k][1][0];            // window-edge waves: any value (those rows are not kept)
+      below[k] = ring[k][1][RJ - 1];
+      if (w > 0) above[k] = lds[buf][w - 1][2 * k + 1][lane];
+      if (w < WJ - 1) below[k] = lds[buf][w + 1][2 * k][lane];
+    });
+    if (i + NS + 1 <= ie + NS - 1) load_plane(i + NS + 1, un);   // u(ie - 1 + NS) is the last plane a kept result depends on
+    static_for<NS>([&](auto kc) {
+      constexpr int k = kc;                // stage k + 1: v_{k+1}(i + NS - k - 1) from ring[k]
+      if constexpr (k + 1 < NS) stage(ring[k][0], ring[k][1], ring[k][2], above[k], below[k], i + NS - k - 1, ring[k + 1][2]);
+      else stage(ring[k][0], ring[k][1], ring[k][2], above[k], below[k], i, wres);
+    });
     if (i >= ib && lane_keep) {
       char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
       static_for<RJ>([&](auto rc) {
@@ -174,10 +192,9 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
         if (row_keep[r]) __builtin_nontemporal_store(wres[r], reinterpret_cast<V*>(obase + (rowb[r] + lane_b)));
       });
     }
-    static_for<RJ>([&](auto rc) {
-      constexpr int r = rc;
-      u0[r] = u1[r]; u1[r] = u2[r];
-      vm[r] = v0[r]; v0[r] = v1[r];
+    static_for<NS>([&](auto kc) {
+      constexpr int k = kc;
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][0][r] = ring[k][1][r]; ring[k][1][r] = ring[k][2][r]; });
     });
   }
 }
@@ -204,11 +221,11 @@ inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* in, c
   return true;
 }
 
-template <class Body, class T, class FP, int RJ, int WJ, int MINW>
+template <class Body, class T, class FP, int NS, int RJ, int WJ, int MINW>
 inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
                                int chunk_req) {
   constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T);
-  constexpr int KEEPJ = RJ * WJ - 4, KEEPK = kWave * VK - G;
+  constexpr int KEEPJ = RJ * WJ - 2 * NS, KEEPK = kWave * VK - G;
   March2Params<T> P{};
   P.in = static_cast<const T*>(in);
   P.out = static_cast<T*>(out);
@@ -233,35 +250,52 @@ inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t*
   P.chunk = (int32_t)chunk;
   const int64_t blocks = (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk);
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
-  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, RJ, WJ, MINW>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P, body);
+  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, NS, RJ, WJ, MINW>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P,
+                     body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;
 }
 
-template <class Body, class T, class FP>
+template <class Body, class T, class FP, int NS>
 inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
                          int chunk_req) {
   if (!march2_eligible<T, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
   if (geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;   // pure copies: leave to the plain path
-  // window shape: NEPTUNE_HIP_MARCH2 = 0..4 picks one for measurements (tools/twostep_bench.py)
+  // window shape: NEPTUNE_HIP_MARCH2 = 0..3 picks one for measurements (tools/twostep_bench.py)
   static const int shape = [] { const char* e = getenv("NEPTUNE_HIP_MARCH2"); return e ? atoi(e) : 0; }();
-  // Measured on 1024^3 fp64, 7-point operator, 128-plane chunks, steps/s against one apply per pass (2.82 ms/step),
-  // profiles/r02_twostep.txt:  rows per lane x waves  3x16: 1.79x (108 VGPRs)   7x8: 1.81x (228 VGPRs)   6x8: 1.75x
-  // 2x16: 1.74x   5x8: 1.75x   4x8: 1.59x   4x16 (spills): 1.51x.  Default: 3x16 -- sixteen waves keep 48 KiB of row loads
-  // in flight per CU with registers to spare for bodies heavier than the Laplacian.
-  switch (shape) {
-    default:
-    case 0: return launch_march2_shape<Body, T, FP, 3, 16, 1>(body, g, in, out, stream, chunk_req);
+  if constexpr (NS == 2) {
+    // Measured on 1024^3 fp64, 7-point operator, 128-plane chunks, steps/s against one apply per pass (2.82 ms/step),
+    // profiles/r02_twostep.txt:  rows per lane x waves  3x16: 1.79x (108 VGPRs)   7x8: 1.81x (228 VGPRs)   6x8: 1.75x
+    // 2x16: 1.74x   5x8: 1.75x   4x8: 1.59x   4x16 (spills): 1.51x.  Default: 3x16 -- sixteen waves keep 48 KiB of row
+    // loads in flight per CU with registers to spare for bodies heavier than the Laplacian.
+    switch (shape) {
+      default:
+      case 0: return launch_march2_shape<Body, T, FP, 2, 3, 16, 1>(body, g, in, out, stream, chunk_req);
 #if NEPTUNE_HIP_FULL_VARIANTS
-    case 1: return launch_march2_shape<Body, T, FP, 7, 8, 1>(body, g, in, out, stream, chunk_req);
-    case 2: return launch_march2_shape<Body, T, FP, 4, 8, 1>(body, g, in, out, stream, chunk_req);
-    case 3: return launch_march2_shape<Body, T, FP, 2, 16, 1>(body, g, in, out, stream, chunk_req);
+      case 1: return launch_march2_shape<Body, T, FP, 2, 7, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 2: return launch_march2_shape<Body, T, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 3: return launch_march2_shape<Body, T, FP, 2, 2, 16, 1>(body, g, in, out, stream, chunk_req);
 #endif
+    }
+  } else {
+    // three applies per pass: three rings of three planes per lane
+    switch (shape) {
+      default:
+      case 0: return launch_march2_shape<Body, T, FP, 3, 3, 12, 1>(body, g, in, out, stream, chunk_req);
+#if NEPTUNE_HIP_FULL_VARIANTS
+      case 1: return launch_march2_shape<Body, T, FP, 3, 2, 12, 1>(body, g, in, out, stream, chunk_req);
+      case 2: return launch_march2_shape<Body, T, FP, 3, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 3: return launch_march2_shape<Body, T, FP, 3, 5, 8, 1>(body, g, in, out, stream, chunk_req);
+#endif
+    }
   }
 }
 
-template <class Body, class T, int RANK, int NIN, class FP>
-inline int launch_apply_twice(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+// what callers use: NS (2 or 3) chained applies of `body` in one pass if the footprint and the geometry allow it, else
+// NEPTUNE_HIP_EUNSUPPORTED (the caller then launches the apply NS times); never instantiates the kernel for a footprint it
+// cannot serve
+template <class Body, class T, int RANK, int NIN, class FP, int NS = 2>
+inline int launch_apply_chain(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                               hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
   if constexpr (RANK == 3 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX &&
                 FP::HALO_MASK == 1u) {
@@ -269,10 +303,20 @@ inline int launch_apply_twice(const Body& body, const neptune_hip_apply_geom_t* 
     if (cfg && cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_EUNSUPPORTED;
     const int rc = geom_validate(g);
     if (rc != NEPTUNE_HIP_OK) return rc;
-    return launch_march2<Body, T, FP>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
+    return launch_march2<Body, T, FP, NS>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
   } else {
     return NEPTUNE_HIP_EUNSUPPORTED;
   }
+}
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int launch_apply_twice(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                              hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+  return launch_apply_chain<Body, T, RANK, NIN, FP, 2>(body, g, in, out, stream, cfg);
+}
+template <class Body, class T, int RANK, int NIN, class FP>
+inline int launch_apply_thrice(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                               hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
+  return launch_apply_chain<Body, T, RANK, NIN, FP, 3>(body, g, in, out, stream, cfg);
 }
 
 }  // namespace neptune_hip

@@ -575,6 +575,14 @@ struct Emitter {
                      << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
                      << "  return neptune_hip::launch_apply_twice<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
                      << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n"
+                     << "extern \"C\" int " << ai.geom_symbol << "3"
+                     << "(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,\n"
+                     << "    const neptune_hip_launch_cfg_t* cfg) {\n"
+                     << "  if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;\n"
+                     << "  const int rc = neptune_hip::geom_check_radius(g, kTopRadius_" << tag << ");\n"
+                     << "  if (rc != NEPTUNE_HIP_OK) return rc;\n"
+                     << "  return neptune_hip::launch_apply_thrice<Body_" << tag << ", " << ctype(res.elem) << ", " << res.bounds.rank() << ", " << nin
+                     << ", FP_" << tag << ">(Body_" << tag << "{}, g, in, out, (hipStream_t)stream, cfg);\n}\n"
                      << "// march tiles this module holds for that entry (plan-time tuning: neptune_hip_autotune_fn)\n"
                      << "extern \"C\" int " << ai.geom_symbol << "_variants(int rank) { return neptune_hip::march_variant_count(rank); }\n\n";
         info.applies.push_back(ai);
@@ -661,9 +669,9 @@ struct Emitter {
                 ge << "}";
               }
               ge << "};\n";
-              const char* names[2] = {"", "2"};
-              const char* fns[2] = {"launch_apply", "launch_apply_twice"};
-              for (int v = 0; v < 2; ++v)
+              const char* names[3] = {"", "2", "3"};
+              const char* fns[3] = {"launch_apply", "launch_apply_twice", "launch_apply_thrice"};
+              for (int v = 0; v < 3; ++v)
                 ge << "extern \"C\" int " << ai.geom_symbol << names[v]
                    << "(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, void* stream,\n"
                    << "    const neptune_hip_launch_cfg_t* cfg) {\n"

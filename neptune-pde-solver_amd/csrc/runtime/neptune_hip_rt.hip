@@ -200,6 +200,7 @@ void neptune_hip_init(int device) {
 // state of neptune_hip_step_loop (defined further down)
 namespace {
 struct LoopKey {
+  neptune_hip_apply_fn fn3;   // three chained applies in one launch (<tag>__geom3), or nullptr
   neptune_hip_apply_fn fn2;   // two chained applies in one launch (a lowered apply's <tag>__geom2), or nullptr
   neptune_hip_apply_fn fn;
   int body;
@@ -439,11 +440,12 @@ int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const
   return NEPTUNE_HIP_EINVAL;
 }
 
-// two chained applies of a built-in body in one pass over HBM (csrc/kernels/apply_march2.hpp)
-int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
-                               void* stream, const neptune_hip_launch_cfg_t* cfg) {
+// two or three chained applies of a built-in body in one pass over HBM (csrc/kernels/apply_march2.hpp)
+int neptune_hip_apply_chain_builtin(int body, int applies, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                                    void* stream, const neptune_hip_launch_cfg_t* cfg) {
   if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
   if (body < 0 || body >= NEPTUNE_HIP_BODY_COUNT) return NEPTUNE_HIP_EINVAL;
+  if (applies != 2 && applies != 3) return NEPTUNE_HIP_EUNSUPPORTED;
   int rc = geom_validate(g);
   if (rc != NEPTUNE_HIP_OK) return rc;
   if (g->num_inputs != 1 || !in[0]) return NEPTUNE_HIP_EUNSUPPORTED;
@@ -453,21 +455,29 @@ int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, cons
   hipStream_t s = as_stream(stream);
   switch (body) {
     case NEPTUNE_HIP_BODY_LAP3D7_F64:
-      return launch_apply_twice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg);
-    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 2-D, 1-D and box bodies: two launches
+      return applies == 2 ? launch_apply_twice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg)
+                          : launch_apply_thrice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg);
+    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 2-D, 1-D and box bodies: one launch per apply
   }
+}
+int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
+                               void* stream, const neptune_hip_launch_cfg_t* cfg) {
+  return neptune_hip_apply_chain_builtin(body, 2, g, in, out, stream, cfg);
 }
 
 // ---------------------------------------------------------------- hipGraph step loop
 namespace {
-// out = A(A(in)) in one launch when the body and the geometry allow it (else NEPTUNE_HIP_EUNSUPPORTED)
-int loop_launch2(const LoopKey& k, int from, int to) {
+// `applies` (2 or 3) chained applies in one launch when the body and the geometry allow it (else NEPTUNE_HIP_EUNSUPPORTED)
+int loop_launch_chain(const LoopKey& k, int applies, int from, int to) {
   if (k.g.num_inputs != 1) return NEPTUNE_HIP_EUNSUPPORTED;
   const void* ins[1] = {k.fields[from]};
   const neptune_hip_launch_cfg_t* cfg = (k.cfg.kernel || k.cfg.variant >= 0 || k.cfg.chunk || k.cfg.flags) ? &k.cfg : nullptr;
   if (cfg && (cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT || cfg->variant >= 0)) return NEPTUNE_HIP_EUNSUPPORTED;  // an explicit tile was asked for
-  if (k.fn) return k.fn2 ? k.fn2(&k.g, ins, k.fields[to], (void*)k.stream, cfg) : NEPTUNE_HIP_EUNSUPPORTED;
-  return neptune_hip_apply2_builtin(k.body, &k.g, ins, k.fields[to], (void*)k.stream, cfg);
+  if (k.fn) {
+    neptune_hip_apply_fn f = applies == 2 ? k.fn2 : k.fn3;
+    return f ? f(&k.g, ins, k.fields[to], (void*)k.stream, cfg) : NEPTUNE_HIP_EUNSUPPORTED;
+  }
+  return neptune_hip_apply_chain_builtin(k.body, applies, &k.g, ins, k.fields[to], (void*)k.stream, cfg);
 }
 int loop_launch(const LoopKey& k, int from, int to) {
   const void* ins[NEPTUNE_HIP_MAX_INPUTS];
@@ -487,6 +497,12 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
 int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, int body, const neptune_hip_apply_geom_t* g,
                                 void* const fields[2], const void* const* in, int64_t steps, void* stream,
                                 const neptune_hip_launch_cfg_t* cfg) {
+  return neptune_hip_step_loop_chain(fn, fn2, nullptr, body, g, fields, in, steps, stream, cfg);
+}
+
+int neptune_hip_step_loop_chain(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn2, neptune_hip_apply_fn fn3, int body,
+                                const neptune_hip_apply_geom_t* g, void* const fields[2], const void* const* in, int64_t steps,
+                                void* stream, const neptune_hip_launch_cfg_t* cfg) {
   if (!g || !fields || !fields[0] || !fields[1] || fields[0] == fields[1] || steps < 0) return NEPTUNE_HIP_EINVAL;
   if (g->num_inputs < 1 || g->num_inputs > NEPTUNE_HIP_MAX_INPUTS) return NEPTUNE_HIP_EINVAL;
   if (g->num_inputs > 1 && !in) return NEPTUNE_HIP_EINVAL;
@@ -495,6 +511,7 @@ int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn
   memset(&key, 0, sizeof(key));  // padding too: keys are compared with memcmp
   key.fn = fn;
   key.fn2 = fn ? fn2 : nullptr;
+  key.fn3 = fn ? fn3 : nullptr;
   key.body = fn ? -1 : body;
   key.g = *g;
   key.fields[0] = fields[0];
@@ -524,15 +541,34 @@ int neptune_hip_step_loop_pairs(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn
     return rc;
   };
 
-  // Two steps per pass over HBM while an EVEN number of such pair launches fits: each pair launch moves the state to
-  // the other field, so an even count brings it back to fields[0] and the remaining steps (fewer than four) run as
-  // before and end in fields[steps % 2].  The grouping does not change a bit: the same apply is evaluated, cell by cell,
-  // the same number of times on the same operands.
+  // Several steps per pass over HBM.  Every launch -- of one, two or three chained applies -- moves the state to the other
+  // field, and the newest state has to end in fields[steps % 2]:
+  //   * triples: steps = 3 T + r needs T + r launches, and T + r = steps (mod 2) always: T triples, then r < 3 single steps;
+  //   * pairs (when the triple entry does not exist or refuses): an EVEN number of pair launches brings the state back to
+  //     fields[0], the remaining < 4 steps run as before.
+  // The grouping does not change a bit: the same apply is evaluated, cell by cell, the same number of times on the same
+  // operands.  NEPTUNE_HIP_NO_PAIRS=1 keeps one apply per pass, NEPTUNE_HIP_NO_TRIPLES=1 stops at two.
+  if (steps >= 3 && !getenv("NEPTUNE_HIP_NO_PAIRS") && !getenv("NEPTUNE_HIP_NO_TRIPLES")) {
+    const int64_t triples = steps / 3;
+    int rc3 = loop_launch_chain(key, 3, 0, 1);
+    if (rc3 == NEPTUNE_HIP_OK) {
+      for (int64_t t = 1; t < triples && rc3 == NEPTUNE_HIP_OK; ++t) rc3 = loop_launch_chain(key, 3, (int)(t % 2), (int)((t + 1) % 2));
+      if (rc3 != NEPTUNE_HIP_OK) return finish(rc3);
+      const int base = (int)(triples % 2);
+      for (int64_t s1 = 0; s1 < steps - 3 * triples; ++s1) {
+        const int rc1 = loop_launch(key, (int)((base + s1) % 2), (int)((base + s1 + 1) % 2));
+        if (rc1 != NEPTUNE_HIP_OK) return finish(rc1);
+      }
+      return finish(NEPTUNE_HIP_OK);
+    } else if (rc3 != NEPTUNE_HIP_EUNSUPPORTED) {
+      return finish(rc3);
+    }
+  }
   if (steps >= 4 && !getenv("NEPTUNE_HIP_NO_PAIRS")) {
     const int64_t pairs = (steps / 2) & ~(int64_t)1;
-    int rc2 = loop_launch2(key, 0, 1);
+    int rc2 = loop_launch_chain(key, 2, 0, 1);
     if (rc2 == NEPTUNE_HIP_OK) {
-      for (int64_t p = 1; p < pairs && rc2 == NEPTUNE_HIP_OK; ++p) rc2 = loop_launch2(key, (int)(p % 2), (int)((p + 1) % 2));
+      for (int64_t p = 1; p < pairs && rc2 == NEPTUNE_HIP_OK; ++p) rc2 = loop_launch_chain(key, 2, (int)(p % 2), (int)((p + 1) % 2));
       if (rc2 != NEPTUNE_HIP_OK) return finish(rc2);
       steps -= 2 * pairs;
       if (steps == 0) return finish(NEPTUNE_HIP_OK);

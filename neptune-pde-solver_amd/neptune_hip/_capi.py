@@ -107,6 +107,8 @@ SIGNATURES = {
     "neptune_hip_step_loop": (_i, [_vp, _i, _geom_p, _vpp, _vpp, _i64, _vp, _cfg_p]),
     "neptune_hip_step_loop_pairs": (_i, [_vp, _vp, _i, _geom_p, _vpp, _vpp, _i64, _vp, _cfg_p]),
     "neptune_hip_apply2_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _cfg_p]),
+    "neptune_hip_apply_chain_builtin": (_i, [_i, _i, _geom_p, _vpp, _vp, _vp, _cfg_p]),
+    "neptune_hip_step_loop_chain": (_i, [_vp, _vp, _vp, _i, _geom_p, _vpp, _vpp, _i64, _vp, _cfg_p]),
     "neptune_hip_kernel_name": (C.c_char_p, [_i]),
     "neptune_hip_apply_builtin_variant": (_i, [_i, _geom_p, _cfg_p]),
     "neptune_hip_march_variant_count": (_i, [_i]),

@@ -70,28 +70,31 @@ def step_loop(body, a: DeviceField, b: DeviceField, bounds: Box, steps: int, oth
     is_entry = hasattr(body, "fn")
     fn = C.cast(body.fn, C.c_void_p) if is_entry else None
     fn2 = C.cast(body.fn2, C.c_void_p) if is_entry and getattr(body, "fn2", None) is not None else None
-    rc = lib.neptune_hip_step_loop_pairs(fn, fn2, -1 if is_entry else body, C.byref(g), fields2, ins, steps, st,
+    fn3 = C.cast(body.fn3, C.c_void_p) if is_entry and getattr(body, "fn3", None) is not None else None
+    rc = lib.neptune_hip_step_loop_chain(fn, fn2, fn3, -1 if is_entry else body, C.byref(g), fields2, ins, steps, st,
                                          C.byref(cfg) if cfg is not None else None)
-    _capi.check(rc, "neptune_hip_step_loop_pairs")
+    _capi.check(rc, "neptune_hip_step_loop_chain")
     return b if steps % 2 else a
 
 
 def apply_twice(body, inp: DeviceField, out: DeviceField, bounds: Box, region: Optional[Box] = None,
-                cfg: Optional[_capi.LaunchCfg] = None, stream: Optional[int] = None) -> bool:
-    """out = A(A(inp)) in ONE pass over HBM for apply A (a built-in body id or a lowered apply's geometry-level entry);
-    returns False -- having launched nothing -- when the body or the geometry does not qualify."""
+                cfg: Optional[_capi.LaunchCfg] = None, stream: Optional[int] = None, applies: int = 2) -> bool:
+    """out = A(A(inp)) -- or A(A(A(inp))) with applies=3 -- in ONE pass over HBM for apply A (a built-in body id or a
+    lowered apply's geometry-level entry); returns False -- having launched nothing -- when the body or the geometry does
+    not qualify."""
     lib = _capi.load()
     g = geom_for([inp], out, bounds, region)
     st = current_stream_ptr() if stream is None else stream
     cfg_p = C.byref(cfg) if cfg is not None else None
     if hasattr(body, "fn"):
-        if getattr(body, "fn2", None) is None:
+        f = getattr(body, "fn2" if applies == 2 else "fn3", None)
+        if f is None:
             return False
-        rc = body.fn2(C.byref(g), _in_array([inp]), out.ptr, st, cfg_p)
-        what = body.symbol + "2"
+        rc = f(C.byref(g), _in_array([inp]), out.ptr, st, cfg_p)
+        what = body.symbol + str(applies)
     else:
-        rc = lib.neptune_hip_apply2_builtin(body, C.byref(g), _in_array([inp]), out.ptr, st, cfg_p)
-        what = "neptune_hip_apply2_builtin"
+        rc = lib.neptune_hip_apply_chain_builtin(body, applies, C.byref(g), _in_array([inp]), out.ptr, st, cfg_p)
+        what = "neptune_hip_apply_chain_builtin"
     if rc == _capi.EUNSUPPORTED:
         return False
     _capi.check(rc, what)

@@ -157,8 +157,10 @@ class GeomEntry:
         # two chained applies in one pass over HBM (csrc/kernels/apply_march2.hpp); returns NEPTUNE_HIP_EUNSUPPORTED for
         # footprints / geometries it cannot take, and step loops then fall back to one launch per step
         self.fn2 = getattr(module.lib, self.symbol + "2", None)
-        if self.fn2 is not None:
-            self.fn2.restype, self.fn2.argtypes = C.c_int, self.fn.argtypes
+        self.fn3 = getattr(module.lib, self.symbol + "3", None)
+        for f in (self.fn2, self.fn3):
+            if f is not None:
+                f.restype, f.argtypes = C.c_int, self.fn.argtypes
 
     def __call__(self, geom, in_array, out_ptr, stream, cfg=None) -> int:
         return self.fn(C.byref(geom), in_array, out_ptr, stream, C.byref(cfg) if cfg is not None else None)

@@ -1,6 +1,6 @@
-"""Two applies per pass over HBM (csrc/kernels/apply_march2.hpp, neptune_hip_apply2_builtin, <tag>__geom2,
-neptune_hip_step_loop_pairs): out = A(A(in)) computed in one launch must equal two launches bit for bit -- the same
-operations on the same operands -- and both must equal the oracle's chained applies."""
+"""Two or three applies per pass over HBM (csrc/kernels/apply_march2.hpp, neptune_hip_apply_chain_builtin,
+<tag>__geom2 / __geom3, neptune_hip_step_loop_chain): out = A(A(in)) or A(A(A(in))) computed in one launch must equal
+separate launches bit for bit -- the same operations on the same operands -- and both must equal the oracle's chained applies."""
 import ctypes as C
 
 import numpy as np
@@ -57,8 +57,9 @@ def test_every_window_shape_in_a_child_process(window, built_libs):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
 
 
+@pytest.mark.parametrize("applies", [2, 3])
 @pytest.mark.parametrize("shape,origin,bounds", CASES)
-def test_two_applies_in_one_pass_equal_two_launches_and_the_oracle(nh, shape, origin, bounds):
+def test_two_applies_in_one_pass_equal_two_launches_and_the_oracle(nh, shape, origin, bounds, applies):
     body = nh.capi.BODY_LAP3D7_F64
     lb = origin or [0, 0, 0]
     u = helpers.hash_field(shape, np.float64, seed=23)
@@ -73,13 +74,18 @@ def test_two_applies_in_one_pass_equal_two_launches_and_the_oracle(nh, shape, or
         b = ([l + x for l, x in zip(lb, bounds[0])], [l + x for l, x in zip(lb, bounds[1])])
     nh.apply.apply_builtin(body, [fin], mid, b)
     nh.apply.apply_builtin(body, [mid], two, b)
+    o = helpers.oracle_entry("3d7", helpers.oracle_entry("3d7", u, origin=lb, bounds=b), origin=lb, bounds=b)
+    if applies == 3:                         # a third launch / oracle apply on top
+        three = nh.fields.DeviceField.empty_like(fin)
+        nh.apply.apply_builtin(body, [two], three, b)
+        two = three
+        o = helpers.oracle_entry("3d7", o, origin=lb, bounds=b)
     for chunk in (0, 5):
         one.tensor.fill_(float("nan"))
-        assert nh.apply.apply_twice(body, fin, one, b, cfg=nh.apply.make_cfg(chunk=chunk))
+        assert nh.apply.apply_twice(body, fin, one, b, cfg=nh.apply.make_cfg(chunk=chunk), applies=applies)
         nh.torch.cuda.synchronize()
         got, want = one.numpy(), two.numpy()
         assert helpers.bits_equal(got, want), f"chunk {chunk}\n" + helpers.mismatch_report(got, want)
-    o = helpers.oracle_entry("3d7", helpers.oracle_entry("3d7", u, origin=lb, bounds=b), origin=lb, bounds=b)
     assert helpers.bits_equal(two.numpy(), o), helpers.mismatch_report(two.numpy(), o)
 
 
@@ -97,7 +103,7 @@ def test_geometries_the_pair_kernel_cannot_take_are_refused_not_run(nh):
     assert nh.apply.apply_twice(nh.capi.BODY_LAP2D5_F64, f2, nh.fields.DeviceField.empty_like(f2), ([1, 1], [63, 255])) is False
 
 
-@pytest.mark.parametrize("steps", [4, 5, 6, 7, 9, 12, 37])
+@pytest.mark.parametrize("steps", [3, 4, 5, 6, 7, 9, 12, 37])
 def test_step_loop_uses_pairs_and_ends_in_the_documented_field(nh, steps, monkeypatch):
     """neptune_hip_step_loop with pair launches == the same loop forced to single launches == the oracle's chain; the
     newest state is in fields[steps % 2] either way"""
@@ -111,12 +117,14 @@ def test_step_loop_uses_pairs_and_ends_in_the_documented_field(nh, steps, monkey
     nh.torch.cuda.synchronize()
     assert res is (b if steps % 2 else a)
     got = res.numpy().copy()
-    monkeypatch.setenv("NEPTUNE_HIP_NO_PAIRS", "1")
-    a2 = nh.fields.DeviceField.from_numpy(u)
-    b2 = nh.fields.DeviceField.empty_like(a2)
-    res2 = nh.apply.step_loop(body, a2, b2, bounds, steps)
-    nh.torch.cuda.synchronize()
-    assert helpers.bits_equal(got, res2.numpy())
+    for env in ("NEPTUNE_HIP_NO_TRIPLES", "NEPTUNE_HIP_NO_PAIRS"):     # two per pass only, then one per pass
+        monkeypatch.setenv(env, "1")
+        a2 = nh.fields.DeviceField.from_numpy(u)
+        b2 = nh.fields.DeviceField.empty_like(a2)
+        res2 = nh.apply.step_loop(body, a2, b2, bounds, steps)
+        nh.torch.cuda.synchronize()
+        assert res2 is (b2 if steps % 2 else a2)
+        assert helpers.bits_equal(got, res2.numpy()), env
     o = u
     for _ in range(steps):
         o = helpers.oracle_entry("3d7", o)
@@ -132,7 +140,7 @@ def test_fused_euler_step_of_a_lowered_module_two_steps_per_pass(nh, tmp_path, m
     text = helpers.stencil_module("3d7", list(shape), time_step=0.125)
     mod = lowering.compile_module(text)
     entry = mod.geom_entry("step")
-    assert entry.symbol == "step_ta0__geom" and entry.fn2 is not None
+    assert entry.symbol == "step_ta0__geom" and entry.fn2 is not None and entry.fn3 is not None
     u = helpers.hash_field(shape, np.float64, seed=8)
     m = helpers.oracle.Module.parse(text)
     o1, o2 = np.zeros(shape), np.zeros(shape)
@@ -144,6 +152,11 @@ def test_fused_euler_step_of_a_lowered_module_two_steps_per_pass(nh, tmp_path, m
     assert nh.apply.apply_twice(entry, fin, out, bounds)
     nh.torch.cuda.synchronize()
     assert helpers.bits_equal(out.numpy(), o2), helpers.mismatch_report(out.numpy(), o2)
+    o3 = np.zeros(shape)
+    m.call("step", o3, o2)
+    assert nh.apply.apply_twice(entry, fin, out, bounds, applies=3)
+    nh.torch.cuda.synchronize()
+    assert helpers.bits_equal(out.numpy(), o3), helpers.mismatch_report(out.numpy(), o3)
     # the operator itself (lap3d_0__geom2) and a 6-step loop of the Euler step
     lap = mod.geom_entry("lap3d")
     assert lap.fn2 is not None

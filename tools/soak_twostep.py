@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Soak for the two-applies-per-pass kernel (csrc/kernels/apply_march2.hpp): random shapes (rows of whole 64-byte
-granules), logical origins, apply bounds, plane-range launch regions and chunk lengths; out = A(A(in)) in one launch must
-equal two launches of the march kernel AND the oracle's chained applies, bit for bit.  The window shape is chosen with
+"""Soak for the several-applies-per-pass kernel (csrc/kernels/apply_march2.hpp): random shapes (rows of whole 64-byte
+granules), logical origins, apply bounds, plane-range launch regions and chunk lengths; out = A(A(in)) or A(A(A(in))) in one
+launch must equal separate launches of the march kernel AND the oracle's chained applies, bit for bit.  The window shape is chosen with
 NEPTUNE_HIP_MARCH2 (read once per process): run once per shape.   usage: tools/soak_twostep.py [cases] [seed]"""
 import os
 import sys
@@ -46,14 +46,18 @@ def main():
             regions.append(([a, 0, 0], [b, shape[1], shape[2]]))
         empty = any(l >= h for l, h in zip(lb, ub))
         o = None
+        applies = int(rng.choice([2, 3]))
         for region in regions:
-            # reference: two launches; the second one's region is the same plane range, the first covers the whole field
+            # reference: separate launches; the last one's region is the same plane range, the others cover the whole field
             apply.apply_builtin(body, [fin], mid, (lb, ub))
+            if applies == 3:
+                apply.apply_builtin(body, [mid], one, (lb, ub))
+                mid, one = one, mid
             two.tensor.fill_(float("nan"))
             apply.apply_builtin(body, [mid], two, (lb, ub), region=region)
             for chunk in (0, 1, 3, int(rng.integers(2, 40))):
                 one.tensor.fill_(float("nan"))
-                ok = apply.apply_twice(body, fin, one, (lb, ub), region=region, cfg=apply.make_cfg(chunk=chunk))
+                ok = apply.apply_twice(body, fin, one, (lb, ub), region=region, cfg=apply.make_cfg(chunk=chunk), applies=applies)
                 if not ok:
                     refused += 1
                     assert empty, f"case {c}: refused a geometry that qualifies: shape {shape} bounds {lb} {ub}"
@@ -67,8 +71,10 @@ def main():
                     sys.exit(1)
             if region is None and not empty:
                 o = helpers.oracle_entry("3d7", helpers.oracle_entry("3d7", u, origin, (lb, ub)), origin, (lb, ub))
-                assert helpers.bits_equal(two.numpy(), o), f"case {c}: two launches differ from the oracle"
-    print(f"SOAK_TWOSTEP_OK window={os.environ.get('NEPTUNE_HIP_MARCH2', '0')} cases={cases} seed={seed} pair_launches={launches} "
+                if applies == 3:
+                    o = helpers.oracle_entry("3d7", o, origin, (lb, ub))
+                assert helpers.bits_equal(two.numpy(), o), f"case {c}: separate launches differ from the oracle"
+    print(f"SOAK_TWOSTEP_OK window={os.environ.get('NEPTUNE_HIP_MARCH2', '0')} cases={cases} seed={seed} chain_launches={launches} "
           f"refused_empty={refused} seconds={time.time() - t0:.0f}")
 
 

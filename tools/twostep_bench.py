@@ -23,7 +23,7 @@ def main():
     only_builtin = "--builtin-only" in sys.argv
     for n in sizes:
         shape = (n, n, n)
-        steps = 40 if n >= 1024 else 200
+        steps = 42 if n >= 1024 else 204
         bounds = ([1, 1, 1], [n - 1] * 3)
         cases = [("built-in 7-point operator", _capi.BODY_LAP3D7_F64)]
         if not only_builtin:
@@ -35,22 +35,24 @@ def main():
             a.tensor.mul_(1e-3)
             b = fields.DeviceField.empty_like(a)
             row = {"field": f"{n}^3 f64", "body": name, "steps": steps, "shape_variant": os.environ.get("NEPTUNE_HIP_MARCH2", "0"), "chunk": chunk}
-            for label, env in (("one_apply_per_pass", "1"), ("two_applies_per_pass", "")):
+            for label, env in (("one_apply_per_pass", "NEPTUNE_HIP_NO_PAIRS"), ("two_applies_per_pass", "NEPTUNE_HIP_NO_TRIPLES"),
+                               ("three_applies_per_pass", "")):
+                os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
+                os.environ.pop("NEPTUNE_HIP_NO_TRIPLES", None)
                 if env:
-                    os.environ["NEPTUNE_HIP_NO_PAIRS"] = env
-                else:
-                    os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
-                apply.step_loop(body, a, b, bounds, 8, cfg=apply.make_cfg(chunk=chunk) if chunk and not env else None)   # warm: graph capture, clocks
+                    os.environ[env] = "1"
+                apply.step_loop(body, a, b, bounds, 8, cfg=apply.make_cfg(chunk=chunk) if chunk and env != "NEPTUNE_HIP_NO_PAIRS" else None)   # warm: graph capture, clocks
                 a.fill_hash(5)
                 a.tensor.mul_(1e-3)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                apply.step_loop(body, a, b, bounds, steps, cfg=apply.make_cfg(chunk=chunk) if chunk and not env else None)
+                apply.step_loop(body, a, b, bounds, steps, cfg=apply.make_cfg(chunk=chunk) if chunk and env != "NEPTUNE_HIP_NO_PAIRS" else None)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) * 1e3 / steps
                 row[label + "_ms_per_step"] = round(ms, 4)
                 row[label + "_GBps_algorithmic"] = round(2 * n ** 3 * 8 / ms / 1e6, 1)
             row["speedup"] = round(row["one_apply_per_pass_ms_per_step"] / row["two_applies_per_pass_ms_per_step"], 3)
+            row["speedup3"] = round(row["one_apply_per_pass_ms_per_step"] / row["three_applies_per_pass_ms_per_step"], 3)
             print(json.dumps(row), flush=True)
 
 
