@@ -169,3 +169,35 @@ def test_fused_euler_step_of_a_lowered_module_two_steps_per_pass(nh, tmp_path, m
         m.call("step", hb, ha)
         ha, hb = hb, ha
     assert helpers.bits_equal(res.numpy(), ha), helpers.mismatch_report(res.numpy(), ha)
+
+
+@pytest.mark.parametrize("elem", ["f32", "f64"])
+def test_chains_of_a_generated_body_with_an_index_argument(nh, elem, tmp_path, monkeypatch):
+    """fp32 takes other window constants (16 cells per store granule, 4 per lane), and a body that reads an index
+    argument sees a different plane / cell coordinate in every stage: a generated radius-1 star (weighted sum plus the
+    last index) through __geom2 / __geom3 against repeated single launches and the oracle"""
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    import test_multihalo_gpu as mh
+    from neptune_hip import lowering
+    shape = (9, 50, 272 if elem == "f64" else 528)       # > one window along J and K in both element types
+    acc = [(0, o) for o in mh.star(3, 1)]
+    text = mh.module_text(shape, elem, 1, acc, [1, 1, 1], [n - 1 for n in shape])
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("resid")
+    assert entry.fn2 is not None and entry.fn3 is not None
+    npdt = np.float32 if elem == "f32" else np.float64
+    u = (helpers.hash_field(shape, npdt, seed=13) * npdt(0.01)).astype(npdt)
+    bounds = ([1, 1, 1], [n - 1 for n in shape])
+    m = helpers.oracle.Module.parse(text)
+    chain = [u]
+    for _ in range(3):
+        o = np.zeros(shape, npdt)
+        m.call("entry", o, chain[-1])
+        chain.append(o)
+    fin = nh.fields.DeviceField.from_numpy(u)
+    out = nh.fields.DeviceField.empty_like(fin)
+    for applies in (2, 3):
+        out.tensor.fill_(float("nan"))
+        assert nh.apply.apply_twice(entry, fin, out, bounds, applies=applies)
+        nh.torch.cuda.synchronize()
+        assert helpers.bits_equal(out.numpy(), chain[applies]), f"{applies} applies\n" + helpers.mismatch_report(out.numpy(), chain[applies])
