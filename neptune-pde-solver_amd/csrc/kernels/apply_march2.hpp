@@ -199,6 +199,146 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   }
 }
 
+// ---- rank 2 ------------------------------------------------------------------------------------------------
+// The same idea for 2-D fields (d0, d1) -> (I, K): a wave marches DOWN THE ROWS of its column window (one wave span wide,
+// the kept columns whole 64-byte granules as above) with three rows of every stage's input in registers.  There is no J
+// axis, so waves are independent: no LDS, no barrier; PF rows stay in flight per wave instead.  Two or three time steps
+// of a 2-D explicit scheme (the reference's own time-stepping inputs are 1-D / 2-D) cost one read and one write of the
+// field plus 128/120 in columns and 2 NS rows per chunk.
+struct March2R2Params {
+  const void* in;
+  void* out;
+  int32_t N0, N1;          // rows, columns
+  int32_t plb[2], pub[2];
+  int64_t olb[2];
+  int32_t rI0, rI1;        // rows this launch stores
+  int32_t chunk;
+  uint32_t nK;
+};
+
+template <class Body, class T, class FP, int NS, int PF>
+__global__ __launch_bounds__(256) void neptune_apply_march2_rank2(March2R2Params P, Body body) {
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int G = 64 / (int)sizeof(T), SPAN = kWave * VK, KEEPK = SPAN - G;
+  static_assert(NS >= 2 && NS <= 3 && (G / 2) % VK == 0 && G / 2 >= NS, "window constants");
+  static_assert(FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u, "radius-1 star of input 0, rank 2");
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t gw = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);   // global wave id: column windows fastest
+  const uint32_t kt = gw % P.nK, ct = gw / P.nK;
+  const int32_t kw = (int32_t)(kt * KEEPK) - G / 2;
+  const int32_t k0 = kw + lane * VK;
+  const int32_t kc = k0 < 0 ? 0 : (k0 > P.N1 - VK ? P.N1 - VK : k0);
+  const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
+  const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
+  if (ib >= ie) return;
+  const T* in = static_cast<const T*>(P.in);
+  T* out = static_cast<T*>(P.out);
+  auto load_row = [&](int32_t ip) -> V {
+    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    return *reinterpret_cast<const V*>(in + (int64_t)ic * P.N1 + kc);
+  };
+  bool in_k[VK];
+  static_for<VK>([&](auto ec) { constexpr int e = ec; in_k[e] = (k0 + e) >= P.plb[1] && (k0 + e) < P.pub[1]; });
+  const bool lane_keep = k0 >= kw + G / 2 && k0 < kw + SPAN - G / 2 && k0 >= 0 && k0 < P.N1;
+
+  auto stage = [&](const V& lo, const V& ctr, const V& hi, int32_t ip) -> V {
+    V ring[1][3][1] = {{{lo}, {ctr}, {hi}}};
+    T lft[1][1][1][1], rgt[1][1][1][1];
+    V pt[1][1];
+    lft[0][0][0][0] = from_prev<true>(ctr[VK - 1], ctr[0], lane);
+    rgt[0][0][0][0] = from_next<true>(ctr[0], ctr[VK - 1], lane);
+    const bool in_i = ip >= P.plb[0] && ip < P.pub[0];
+    const int64_t li = (int64_t)ip + P.olb[0];
+    V res;
+    static_for<VK>([&](auto ec) {
+      constexpr int e = ec;
+      const int64_t lk = (int64_t)(k0 + e) + P.olb[1];
+      MarchAcc<T, 2, 1, FP, 1, 0, e, false> acc{ring, lft, rgt, pt, li, 0, lk};
+      const T val = body(acc);
+      res[e] = (in_i && in_k[e]) ? val : OutsideOf<Body, T>::apply(body, ctr[e]);
+    });
+    return res;
+  };
+
+  // ring[k]: the three newest rows of stage input k (k = 0: the field itself); un: rows in flight
+  V ring[NS][3];
+  V un[PF];
+  const int32_t i0 = ib - 2 * (NS - 1);
+  ring[0][0] = load_row(i0 + NS - 2);
+  ring[0][1] = load_row(i0 + NS - 1);
+  static_for<PF>([&](auto dc) { constexpr int d = dc; un[d] = load_row(i0 + NS + d); });
+  static_for<NS - 1>([&](auto kc2) { constexpr int k = kc2 + 1; ring[k][0] = ring[0][0]; ring[k][1] = ring[0][0]; });
+  auto step = [&](int32_t i, auto slot_c) {
+    constexpr int slot = slot_c;
+    ring[0][2] = un[slot];
+    if (i + NS + PF <= ie + NS - 1) un[slot] = load_row(i + NS + PF);
+    V w;
+    static_for<NS>([&](auto kc2) {
+      constexpr int k = kc2;
+      if constexpr (k + 1 < NS) ring[k + 1][2] = stage(ring[k][0], ring[k][1], ring[k][2], i + NS - k - 1);
+      else w = stage(ring[k][0], ring[k][1], ring[k][2], i);
+    });
+    if (i >= ib && lane_keep) __builtin_nontemporal_store(w, reinterpret_cast<V*>(out + (int64_t)i * P.N1 + kc));
+    static_for<NS>([&](auto kc2) { constexpr int k = kc2; ring[k][0] = ring[k][1]; ring[k][1] = ring[k][2]; });
+  };
+  for (int32_t i = i0; i < ie; i += PF) {
+    static_for<PF>([&](auto phc) {
+      constexpr int ph = phc;
+      if (i + ph < ie) step(i + ph, phc);
+    });
+  }
+}
+
+template <class T, class FP>
+inline bool march2_rank2_eligible(const neptune_hip_apply_geom_t* g, const void* in, const void* out) {
+  constexpr int G = 64 / (int)sizeof(T);
+  if (!g || g->rank != 2 || g->num_inputs != 1) return false;
+  if (!(FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u)) return false;
+  int64_t n[2];
+  for (int d = 0; d < 2; ++d) {
+    n[d] = g->out_ub[d] - g->out_lb[d];
+    if (g->in_lb[0][d] != g->out_lb[d] || g->in_ub[0][d] != g->out_ub[d]) return false;
+    if (g->lb[d] < g->ub[d] && (g->lb[d] - 1 < g->out_lb[d] || g->ub[d] + 1 > g->out_ub[d])) return false;
+  }
+  if (g->region_lb[1] != 0 || g->region_ub[1] != n[1]) return false;
+  if (n[1] % G != 0 || n[1] < 2 * G || n[0] < 1 || n[0] >= 0x7fffffffLL || n[1] >= 0x7fffffffLL) return false;
+  return (uintptr_t)in % 64 == 0 && (uintptr_t)out % 64 == 0;
+}
+
+template <class Body, class T, class FP, int NS>
+inline int launch_march2_rank2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+                               int chunk_req) {
+  if (!march2_rank2_eligible<T, FP>(g, in, out) || geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;
+  constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T), KEEPK = kWave * VK - G, PF = 4;
+  March2R2Params P{};
+  P.in = in;
+  P.out = out;
+  P.N0 = (int32_t)(g->out_ub[0] - g->out_lb[0]);
+  P.N1 = (int32_t)(g->out_ub[1] - g->out_lb[1]);
+  for (int d = 0; d < 2; ++d) {
+    P.plb[d] = (int32_t)(g->lb[d] - g->out_lb[d]);
+    P.pub[d] = (int32_t)(g->ub[d] - g->out_lb[d]);
+    P.olb[d] = g->out_lb[d];
+  }
+  P.rI0 = (int32_t)g->region_lb[0];
+  P.rI1 = (int32_t)g->region_ub[0];
+  if (P.rI1 <= P.rI0) return NEPTUNE_HIP_OK;
+  P.nK = (uint32_t)((P.N1 + KEEPK - 1) / KEEPK);
+  const int64_t rows = P.rI1 - P.rI0;
+  int64_t chunk = chunk_req > 0 ? chunk_req : 256;
+  // enough waves for the chip (256 CUs x 32 waves), but never chunks so short that the 2 NS warm-up rows dominate
+  while (chunk_req <= 0 && chunk > 32 && (int64_t)P.nK * ((rows + chunk - 1) / chunk) < 8192) chunk /= 2;
+  if (chunk > rows) chunk = rows;
+  P.chunk = (int32_t)chunk;
+  const int64_t waves = (int64_t)P.nK * ((rows + chunk - 1) / chunk);
+  const int64_t blocks = (waves + 3) / 4;
+  if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
+  hipLaunchKernelGGL((neptune_apply_march2_rank2<Body, T, FP, NS, PF>), dim3((uint32_t)blocks), dim3(256), 0, stream, P, body);
+  NEPTUNE_HIP_CHECK(hipGetLastError());
+  return NEPTUNE_HIP_OK;
+}
+
 // host side: can this geometry take the two-steps kernel, and launch it
 template <class T, class FP>
 inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* in, const void* out) {
@@ -304,6 +444,13 @@ inline int launch_apply_chain(const Body& body, const neptune_hip_apply_geom_t* 
     const int rc = geom_validate(g);
     if (rc != NEPTUNE_HIP_OK) return rc;
     return launch_march2<Body, T, FP, NS>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
+  } else if constexpr (RANK == 2 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX &&
+                       FP::HALO_MASK == 1u) {
+    if (!g || !in || !in[0] || !out) return NEPTUNE_HIP_EINVAL;
+    if (cfg && cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_EUNSUPPORTED;
+    const int rc = geom_validate(g);
+    if (rc != NEPTUNE_HIP_OK) return rc;
+    return launch_march2_rank2<Body, T, FP, NS>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
   } else {
     return NEPTUNE_HIP_EUNSUPPORTED;
   }

@@ -200,6 +200,7 @@ void neptune_hip_init(int device) {
 // state of neptune_hip_step_loop (defined further down)
 namespace {
 struct LoopKey {
+  int applies, from0;         // (graph cache only) what one node of the cached graph is, and which field the loop started in
   neptune_hip_apply_fn fn3;   // three chained applies in one launch (<tag>__geom3), or nullptr
   neptune_hip_apply_fn fn2;   // two chained applies in one launch (a lowered apply's <tag>__geom2), or nullptr
   neptune_hip_apply_fn fn;
@@ -457,7 +458,10 @@ int neptune_hip_apply_chain_builtin(int body, int applies, const neptune_hip_app
     case NEPTUNE_HIP_BODY_LAP3D7_F64:
       return applies == 2 ? launch_apply_twice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg)
                           : launch_apply_thrice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg);
-    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 2-D, 1-D and box bodies: one launch per apply
+    case NEPTUNE_HIP_BODY_LAP2D5_F64:
+      return applies == 2 ? launch_apply_twice<builtin::Lap2D5, double, 2, 1, builtin::Lap2D5::FP>(builtin::Lap2D5{}, g, in, out, s, cfg)
+                          : launch_apply_thrice<builtin::Lap2D5, double, 2, 1, builtin::Lap2D5::FP>(builtin::Lap2D5{}, g, in, out, s, cfg);
+    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 1-D and box bodies: one launch per apply
   }
 }
 int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
@@ -541,88 +545,94 @@ int neptune_hip_step_loop_chain(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn
     return rc;
   };
 
+  // `count` launches of `applies` chained applies each (1 = the plain apply), the first one reading fields[from0], every launch
+  // moving the state to the other field.  The first launch is a plain one (it validates the request and warms the
+  // launcher's one-time queries outside of stream capture); from 16 more on, a ping-pong pair of launches is captured
+  // once into a hipGraph of 16 kernel nodes and replayed (graphs cached by geometry, pointers, configuration and kind), so
+  // that small fields are not bound by launch overhead.  Returns NEPTUNE_HIP_EUNSUPPORTED from the FIRST launch untouched
+  // (nothing has run then).
+  auto run_launches = [&](int applies, int64_t count, int from0) -> int {
+    if (count <= 0) return NEPTUNE_HIP_OK;
+    auto launch = [&](int from, int to) { return applies == 1 ? loop_launch(key, from, to) : loop_launch_chain(key, applies, from, to); };
+    const int b0 = from0, b1 = from0 ^ 1;
+    int rc = launch(b0, b1);
+    if (rc != NEPTUNE_HIP_OK) return rc;
+    int64_t done = 1;
+    constexpr int kPairs = 8;  // ping-pong pairs per graph: 16 kernel nodes amortise one graph launch
+    if (count - done >= 2 * kPairs) {
+      LoopKey gkey = key;
+      gkey.applies = applies;
+      gkey.from0 = from0;
+      RuntimeState& s = rt();
+      std::lock_guard<std::mutex> lk(s.mu);
+      LoopGraph* slot = nullptr;
+      for (auto& e : g_loops)
+        if (e.exec && memcmp(&e.key, &gkey, sizeof(gkey)) == 0) slot = &e;
+      if (!slot) {
+        slot = &g_loops[0];
+        for (auto& e : g_loops)
+          if (e.stamp < slot->stamp) slot = &e;  // least recently used (empty slots have stamp 0)
+        if (slot->exec) {
+          (void)hipGraphExecDestroy(slot->exec);
+          (void)hipGraphDestroy(slot->graph);
+          slot->exec = nullptr;
+          slot->graph = nullptr;
+        }
+        // the pair (b1 -> b0, b0 -> b1) leaves the state where it found it, so it can be replayed any number of times
+        NEPTUNE_HIP_CHECK(hipStreamBeginCapture(key.stream, hipStreamCaptureModeRelaxed));
+        int r1 = NEPTUNE_HIP_OK, r2 = NEPTUNE_HIP_OK;
+        for (int p = 0; p < kPairs && r1 == NEPTUNE_HIP_OK && r2 == NEPTUNE_HIP_OK; ++p) {
+          r1 = launch(b1, b0);
+          r2 = launch(b0, b1);
+        }
+        hipGraph_t graph = nullptr;
+        NEPTUNE_HIP_CHECK(hipStreamEndCapture(key.stream, &graph));
+        if (r1 != NEPTUNE_HIP_OK || r2 != NEPTUNE_HIP_OK || !graph) {
+          if (graph) (void)hipGraphDestroy(graph);
+          return r1 != NEPTUNE_HIP_OK ? r1 : (r2 != NEPTUNE_HIP_OK ? r2 : NEPTUNE_HIP_EINVAL);
+        }
+        NEPTUNE_HIP_CHECK(hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0));
+        slot->graph = graph;
+        slot->key = gkey;
+      }
+      slot->stamp = ++g_loop_clock;
+      for (; count - done >= 2 * kPairs; done += 2 * kPairs) NEPTUNE_HIP_CHECK(hipGraphLaunch(slot->exec, key.stream));
+    }
+    for (; done < count; ++done) {
+      rc = launch((int)((from0 + done) % 2), (int)((from0 + done + 1) % 2));
+      if (rc != NEPTUNE_HIP_OK) return rc == NEPTUNE_HIP_EUNSUPPORTED ? NEPTUNE_HIP_EINVAL : rc;
+    }
+    return NEPTUNE_HIP_OK;
+  };
+
   // Several steps per pass over HBM.  Every launch -- of one, two or three chained applies -- moves the state to the other
   // field, and the newest state has to end in fields[steps % 2]:
   //   * triples: steps = 3 T + r needs T + r launches, and T + r = steps (mod 2) always: T triples, then r < 3 single steps;
   //   * pairs (when the triple entry does not exist or refuses): an EVEN number of pair launches brings the state back to
-  //     fields[0], the remaining < 4 steps run as before.
+  //     fields[0], the remaining < 4 steps run as single launches.
   // The grouping does not change a bit: the same apply is evaluated, cell by cell, the same number of times on the same
   // operands.  NEPTUNE_HIP_NO_PAIRS=1 keeps one apply per pass, NEPTUNE_HIP_NO_TRIPLES=1 stops at two.
-  if (steps >= 3 && !getenv("NEPTUNE_HIP_NO_PAIRS") && !getenv("NEPTUNE_HIP_NO_TRIPLES")) {
+  // Chaining pays where a step is bound by HBM: a field that stays in the 256 MiB memory-side cache between steps gains
+  // nothing from saved passes and loses to the chain kernels' longer dependent march (measured, profiles/r02_twostep.txt:
+  // 128^3 and 1024^2 fp64 are faster one apply per launch, 256^3 and 2048^2 are faster chained: the line is 4e6 cells).
+  int64_t cells = 1;
+  for (int d = 0; d < g->rank; ++d) cells *= g->ub[d] > g->lb[d] ? g->ub[d] - g->lb[d] : 0;
+  const char* min_cells_env = getenv("NEPTUNE_HIP_CHAIN_MIN_CELLS");
+  const int64_t min_cells = min_cells_env ? atoll(min_cells_env) : (int64_t)4000000;
+  const bool chain_ok = cells >= min_cells && !getenv("NEPTUNE_HIP_NO_PAIRS");
+  if (steps >= 3 && chain_ok && !getenv("NEPTUNE_HIP_NO_TRIPLES")) {
     const int64_t triples = steps / 3;
-    int rc3 = loop_launch_chain(key, 3, 0, 1);
-    if (rc3 == NEPTUNE_HIP_OK) {
-      for (int64_t t = 1; t < triples && rc3 == NEPTUNE_HIP_OK; ++t) rc3 = loop_launch_chain(key, 3, (int)(t % 2), (int)((t + 1) % 2));
-      if (rc3 != NEPTUNE_HIP_OK) return finish(rc3);
-      const int base = (int)(triples % 2);
-      for (int64_t s1 = 0; s1 < steps - 3 * triples; ++s1) {
-        const int rc1 = loop_launch(key, (int)((base + s1) % 2), (int)((base + s1 + 1) % 2));
-        if (rc1 != NEPTUNE_HIP_OK) return finish(rc1);
-      }
-      return finish(NEPTUNE_HIP_OK);
-    } else if (rc3 != NEPTUNE_HIP_EUNSUPPORTED) {
-      return finish(rc3);
-    }
+    const int rc3 = run_launches(3, triples, 0);
+    if (rc3 == NEPTUNE_HIP_OK) return finish(run_launches(1, steps - 3 * triples, (int)(triples % 2)));
+    if (rc3 != NEPTUNE_HIP_EUNSUPPORTED) return finish(rc3);
   }
-  if (steps >= 4 && !getenv("NEPTUNE_HIP_NO_PAIRS")) {
+  if (steps >= 4 && chain_ok) {
     const int64_t pairs = (steps / 2) & ~(int64_t)1;
-    int rc2 = loop_launch_chain(key, 2, 0, 1);
-    if (rc2 == NEPTUNE_HIP_OK) {
-      for (int64_t p = 1; p < pairs && rc2 == NEPTUNE_HIP_OK; ++p) rc2 = loop_launch_chain(key, 2, (int)(p % 2), (int)((p + 1) % 2));
-      if (rc2 != NEPTUNE_HIP_OK) return finish(rc2);
-      steps -= 2 * pairs;
-      if (steps == 0) return finish(NEPTUNE_HIP_OK);
-    } else if (rc2 != NEPTUNE_HIP_EUNSUPPORTED) {
-      return finish(rc2);
-    }
+    const int rc2 = run_launches(2, pairs, 0);
+    if (rc2 == NEPTUNE_HIP_OK) return finish(run_launches(1, steps - 2 * pairs, 0));
+    if (rc2 != NEPTUNE_HIP_EUNSUPPORTED) return finish(rc2);
   }
-  // one plain launch first: validates the request (and warms the launcher's one-time queries) outside
-  // of stream capture, and is step 0 of the loop
-  int rc = loop_launch(key, 0, 1);
-  if (rc != NEPTUNE_HIP_OK) return finish(rc);
-  int64_t done = 1;
-  constexpr int kPairs = 8;  // ping-pong pairs per graph: 16 kernel nodes amortise one graph launch
-  if (steps - done >= 2 * kPairs) {
-    RuntimeState& s = rt();
-    std::lock_guard<std::mutex> lk(s.mu);
-    LoopGraph* slot = nullptr;
-    for (auto& e : g_loops)
-      if (e.exec && memcmp(&e.key, &key, sizeof(key)) == 0) slot = &e;
-    if (!slot) {
-      slot = &g_loops[0];
-      for (auto& e : g_loops)
-        if (e.stamp < slot->stamp) slot = &e;  // least recently used (empty slots have stamp 0)
-      if (slot->exec) {
-        (void)hipGraphExecDestroy(slot->exec);
-        (void)hipGraphDestroy(slot->graph);
-        slot->exec = nullptr;
-        slot->graph = nullptr;
-      }
-      // the pair (1 -> 0, 0 -> 1) leaves the state where it found it, so it can be replayed any number of times
-      NEPTUNE_HIP_CHECK(hipStreamBeginCapture(key.stream, hipStreamCaptureModeRelaxed));
-      int r1 = NEPTUNE_HIP_OK, r2 = NEPTUNE_HIP_OK;
-      for (int p = 0; p < kPairs && r1 == NEPTUNE_HIP_OK && r2 == NEPTUNE_HIP_OK; ++p) {
-        r1 = loop_launch(key, 1, 0);
-        r2 = loop_launch(key, 0, 1);
-      }
-      hipGraph_t graph = nullptr;
-      NEPTUNE_HIP_CHECK(hipStreamEndCapture(key.stream, &graph));
-      if (r1 != NEPTUNE_HIP_OK || r2 != NEPTUNE_HIP_OK || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return finish(r1 != NEPTUNE_HIP_OK ? r1 : (r2 != NEPTUNE_HIP_OK ? r2 : NEPTUNE_HIP_EUNSUPPORTED));
-      }
-      NEPTUNE_HIP_CHECK(hipGraphInstantiate(&slot->exec, graph, nullptr, nullptr, 0));
-      slot->graph = graph;
-      slot->key = key;
-    }
-    slot->stamp = ++g_loop_clock;
-    for (; steps - done >= 2 * kPairs; done += 2 * kPairs) NEPTUNE_HIP_CHECK(hipGraphLaunch(slot->exec, key.stream));
-  }
-  for (; done < steps; ++done) {
-    rc = loop_launch(key, (int)(done % 2), (int)((done + 1) % 2));
-    if (rc != NEPTUNE_HIP_OK) return finish(rc);
-  }
-  return finish(NEPTUNE_HIP_OK);
+  return finish(run_launches(1, steps, 0));
 }
 
 int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t* g, const void* const* in,

@@ -38,6 +38,13 @@ CASES = [
 ]
 
 
+@pytest.fixture(autouse=True)
+def chains_at_every_size(monkeypatch):
+    """step loops chain only fields of >= 4e6 cells by default (smaller ones stay in the memory-side cache and are faster
+    one apply per launch); the parity cases here are small, so lift the threshold"""
+    monkeypatch.setenv("NEPTUNE_HIP_CHAIN_MIN_CELLS", "0")
+
+
 @pytest.fixture(params=["0", "1", "2", "3"], ids=["rows3x16", "rows7x8", "rows4x8", "rows2x16"])
 def window(request, monkeypatch):
     """every window shape the library holds (NEPTUNE_HIP_MARCH2 is read once per process, at the first pair launch:
@@ -98,12 +105,14 @@ def test_geometries_the_pair_kernel_cannot_take_are_refused_not_run(nh):
         assert nh.apply.apply_twice(body, fin, out, ([1, 1, 1], [n - 1 for n in shape])) is False
         nh.torch.cuda.synchronize()
         assert bool((out.tensor == 7.0).all())
-    # 2-D and box bodies: two launches
-    f2 = nh.fields.DeviceField.from_numpy(helpers.hash_field((64, 256), np.float64, seed=1))
-    assert nh.apply.apply_twice(nh.capi.BODY_LAP2D5_F64, f2, nh.fields.DeviceField.empty_like(f2), ([1, 1], [63, 255])) is False
+    # 2-D rows that are not whole granules, and box bodies: one launch per apply
+    f2 = nh.fields.DeviceField.from_numpy(helpers.hash_field((64, 252), np.float64, seed=1))
+    assert nh.apply.apply_twice(nh.capi.BODY_LAP2D5_F64, f2, nh.fields.DeviceField.empty_like(f2), ([1, 1], [63, 251])) is False
+    f3 = nh.fields.DeviceField.from_numpy(helpers.hash_field((8, 16, 256), np.float32, seed=1))
+    assert nh.apply.apply_twice(nh.capi.BODY_LAP3D27_F32, f3, nh.fields.DeviceField.empty_like(f3), ([1, 1, 1], [7, 15, 255])) is False
 
 
-@pytest.mark.parametrize("steps", [3, 4, 5, 6, 7, 9, 12, 37])
+@pytest.mark.parametrize("steps", [3, 4, 5, 6, 7, 9, 12, 37, 60, 71])   # from 17 launches on, 16 are replayed as a graph
 def test_step_loop_uses_pairs_and_ends_in_the_documented_field(nh, steps, monkeypatch):
     """neptune_hip_step_loop with pair launches == the same loop forced to single launches == the oracle's chain; the
     newest state is in fields[steps % 2] either way"""
@@ -117,8 +126,13 @@ def test_step_loop_uses_pairs_and_ends_in_the_documented_field(nh, steps, monkey
     nh.torch.cuda.synchronize()
     assert res is (b if steps % 2 else a)
     got = res.numpy().copy()
-    for env in ("NEPTUNE_HIP_NO_TRIPLES", "NEPTUNE_HIP_NO_PAIRS"):     # two per pass only, then one per pass
-        monkeypatch.setenv(env, "1")
+    for env in ("NEPTUNE_HIP_NO_TRIPLES", "NEPTUNE_HIP_NO_PAIRS", "default threshold"):   # two per pass only, then one per pass
+        if env == "default threshold":
+            monkeypatch.delenv("NEPTUNE_HIP_NO_TRIPLES")
+            monkeypatch.delenv("NEPTUNE_HIP_NO_PAIRS")
+            monkeypatch.delenv("NEPTUNE_HIP_CHAIN_MIN_CELLS")
+        else:
+            monkeypatch.setenv(env, "1")
         a2 = nh.fields.DeviceField.from_numpy(u)
         b2 = nh.fields.DeviceField.empty_like(a2)
         res2 = nh.apply.step_loop(body, a2, b2, bounds, steps)
@@ -201,3 +215,72 @@ def test_chains_of_a_generated_body_with_an_index_argument(nh, elem, tmp_path, m
         assert nh.apply.apply_twice(entry, fin, out, bounds, applies=applies)
         nh.torch.cuda.synchronize()
         assert helpers.bits_equal(out.numpy(), chain[applies]), f"{applies} applies\n" + helpers.mismatch_report(out.numpy(), chain[applies])
+
+
+CASES_2D = [
+    ((40, 256), None, None),
+    ((300, 376), None, None),                          # four column windows, chunk seams along the rows
+    ((33, 128), None, None),                           # one wave span
+    ((70, 256), [-4, 9], None),
+    ((64, 512), None, ([3, 10], [50, 401])),
+]
+
+
+@pytest.mark.parametrize("applies", [2, 3])
+@pytest.mark.parametrize("shape,origin,bounds", CASES_2D)
+def test_rank2_chains_equal_separate_launches_and_the_oracle(nh, shape, origin, bounds, applies):
+    """the 2-D form (waves marching down the rows of a column window, no LDS): 5-point operator"""
+    body = nh.capi.BODY_LAP2D5_F64
+    lb = origin or [0, 0]
+    u = helpers.hash_field(shape, np.float64, seed=29)
+    b = ([l + 1 for l in lb], [l + n - 1 for l, n in zip(lb, shape)]) if bounds is None else \
+        ([l + x for l, x in zip(lb, bounds[0])], [l + x for l, x in zip(lb, bounds[1])])
+    cur = nh.fields.DeviceField.from_numpy(u, lb)
+    o = u
+    for _ in range(applies):
+        nxt = nh.fields.DeviceField.empty_like(cur)
+        nh.apply.apply_builtin(body, [cur], nxt, b)
+        cur = nxt
+        o = helpers.oracle_entry("2d5", o, origin=lb, bounds=b)
+    want = cur.numpy()
+    assert helpers.bits_equal(want, o)
+    fin = nh.fields.DeviceField.from_numpy(u, lb)
+    one = nh.fields.DeviceField.empty_like(fin)
+    for chunk in (0, 7, 64):
+        one.tensor.fill_(float("nan"))
+        assert nh.apply.apply_twice(body, fin, one, b, cfg=nh.apply.make_cfg(chunk=chunk), applies=applies)
+        nh.torch.cuda.synchronize()
+        assert helpers.bits_equal(one.numpy(), want), f"chunk {chunk}\n" + helpers.mismatch_report(one.numpy(), want)
+
+
+@pytest.mark.parametrize("steps", [3, 5, 8, 31, 58])
+def test_rank2_step_loop_and_lowered_euler_step(nh, steps, tmp_path, monkeypatch):
+    """2-D explicit time loop: the built-in operator through neptune_hip_step_loop, and a lowered module's fused Euler step
+    (time_advance + its rhs apply) through its chain entries, against the oracle stepping one call at a time"""
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    from neptune_hip import lowering
+    shape = (48, 256)
+    bounds = ([1, 1], [n - 1 for n in shape])
+    u = helpers.hash_field(shape, np.float64, seed=6) * 0.1
+    a = nh.fields.DeviceField.from_numpy(u)
+    b = nh.fields.DeviceField.empty_like(a)
+    res = nh.apply.step_loop(nh.capi.BODY_LAP2D5_F64, a, b, bounds, steps)
+    nh.torch.cuda.synchronize()
+    o = u
+    for _ in range(steps):
+        o = helpers.oracle_entry("2d5", o)
+    assert res is (b if steps % 2 else a) and helpers.bits_equal(res.numpy(), o)
+    text = helpers.stencil_module("2d5", list(shape), time_step=0.0625)
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("step")
+    assert entry.fn2 is not None and entry.fn3 is not None
+    a = nh.fields.DeviceField.from_numpy(u)
+    b = nh.fields.DeviceField.empty_like(a)
+    res = nh.apply.step_loop(entry, a, b, bounds, steps)
+    nh.torch.cuda.synchronize()
+    m = helpers.oracle.Module.parse(text)
+    ha, hb = u.copy(), np.zeros(shape)
+    for _ in range(steps):
+        m.call("step", hb, ha)
+        ha, hb = hb, ha
+    assert helpers.bits_equal(res.numpy(), ha), helpers.mismatch_report(res.numpy(), ha)
