@@ -22,6 +22,7 @@
 #include "apply_common.hpp"
 #include "apply_direct.hpp"
 #include "apply_march.hpp"
+#include "apply_plane.hpp"
 
 #ifndef NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_HIP_FULL_VARIANTS 0  // generated modules compile the default tile only
@@ -100,6 +101,7 @@ struct MarchVariant {
   int PF;
   bool ntl, ldsj, jk, jhl;
   int KD;
+  bool pln;  // the plane-in-LDS kernel (apply_plane.hpp) for footprints it can run; the same tile of the march kernel otherwise
   const char* name;
 };
 // rank 3: a workgroup is WJ x WK waves, each lane owns RJ rows x 16 B, PF planes in flight.
@@ -126,75 +128,81 @@ struct MarchVariant {
 //   rank 2        : 0  tile_rj4_wj8_wk1      (8192^2 fp64 5-point: 6.15 TB/s),
 //                   2  tile_rj4_wj4_wk1      (two halo inputs: 5.6 TB/s against 4.9 on the march form), and
 //                   1  wk4_pf4, the march form (fields of 2 GiB and more, several halo inputs)
-// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name)
+// X(index, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name)
 #define NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(0, 4, 4, 2, true, true, 2, false, true, false, false, 1, "rj4_wj4_wk2_pf2_lds")    \
-  X(1, 4, 8, 1, true, true, 2, false, true, false, false, 1, "rj4_wj8_wk1_pf2_lds")    \
-  X(2, 2, 8, 1, true, true, 2, false, true, false, true, 1, "rj2_wj8_wk1_pf2_lds_jhl") \
-  X(3, 2, 4, 1, true, true, 2, false, false, false, false, 1, "rj2_wj4_wk1_pf2")      \
-  X(4, 4, 16, 1, true, true, 1, false, true, false, false, 1, "rj4_wj16_wk1_pf1_lds")  \
-  X(5, 2, 8, 1, true, true, 1, false, true, false, true, 1, "rj2_wj8_wk1_pf1_lds_jhl") \
-  X(6, 8, 4, 2, true, true, 1, false, true, false, true, 2, "rj8_wj4_wk2_pf1_lds_jhl_kd2")
+  X(0, 4, 4, 2, true, true, 2, false, true, false, false, 1, false, "rj4_wj4_wk2_pf2_lds")    \
+  X(1, 4, 8, 1, true, true, 2, false, true, false, false, 1, false, "rj4_wj8_wk1_pf2_lds")    \
+  X(2, 2, 8, 1, true, true, 2, false, true, false, true, 1, false, "rj2_wj8_wk1_pf2_lds_jhl") \
+  X(3, 2, 4, 1, true, true, 2, false, false, false, false, 1, false, "rj2_wj4_wk1_pf2")      \
+  X(4, 4, 16, 1, true, true, 1, false, true, false, false, 1, false, "rj4_wj16_wk1_pf1_lds")  \
+  X(5, 2, 8, 1, true, true, 1, false, true, false, true, 1, false, "rj2_wj8_wk1_pf1_lds_jhl") \
+  X(6, 8, 4, 2, true, true, 1, false, true, false, true, 2, false, "rj8_wj4_wk2_pf1_lds_jhl_kd2") \
+  X(7, 4, 8, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj4_wj8_wk1_pf1")
 #define NEPTUNE_MARCH2_DEFAULT(X)                                            \
-  X(0, 4, 8, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj8_wk1")        \
-  X(1, 1, 1, 4, true, true, 4, false, false, false, false, 1, "wk4_pf4")             \
-  X(2, 4, 4, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj4_wk1")
+  X(0, 4, 8, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj4_wj8_wk1")        \
+  X(1, 1, 1, 4, true, true, 4, false, false, false, false, 1, false, "wk4_pf4")             \
+  X(2, 4, 4, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj4_wj4_wk1")
 #if NEPTUNE_HIP_FULL_VARIANTS
 #define NEPTUNE_MARCH3_VARIANTS(X)                \
   NEPTUNE_MARCH3_DEFAULT(X)                                                   \
-  X(7, 4, 4, 1, true, true, 2, false, false, false, false, 1, "rj4_wj4_wk1_pf2") \
-  X(8, 4, 4, 1, false, false, 1, false, false, false, false, 1, "rj4_wj4_wk1_pf1_shfl_plainst") \
-  X(9, 8, 2, 1, true, true, 1, false, false, false, false, 1, "rj8_wj2_wk1_pf1") \
-  X(10, 4, 4, 1, true, true, 1, false, false, false, false, 1, "rj4_wj4_wk1_pf1") \
-  X(11, 4, 4, 1, true, true, 2, false, true, false, false, 1, "rj4_wj4_wk1_pf2_lds") \
-  X(12, 2, 8, 1, true, true, 4, false, true, false, false, 1, "rj2_wj8_wk1_pf4_lds") \
-  X(13, 8, 4, 1, true, true, 1, false, true, false, false, 1, "rj8_wj4_wk1_pf1_lds") \
-  X(14, 8, 4, 2, true, true, 1, false, true, false, false, 1, "rj8_wj4_wk2_pf1_lds") \
-  X(15, 4, 4, 2, true, true, 3, false, true, false, false, 1, "rj4_wj4_wk2_pf3_lds") \
-  X(16, 4, 2, 4, true, true, 2, false, true, false, false, 1, "rj4_wj2_wk4_pf2_lds") \
-  X(17, 2, 16, 1, true, true, 3, false, true, false, false, 1, "rj2_wj16_wk1_pf3_lds") \
-  X(18, 4, 4, 2, true, true, 2, false, true, false, true, 1, "rj4_wj4_wk2_pf2_lds_jhl") \
-  X(19, 4, 8, 1, true, true, 2, false, true, false, true, 1, "rj4_wj8_wk1_pf2_lds_jhl") \
-  X(20, 8, 4, 2, true, true, 1, false, true, false, true, 1, "rj8_wj4_wk2_pf1_lds_jhl") \
-  X(21, 4, 4, 2, true, true, 3, false, true, false, true, 1, "rj4_wj4_wk2_pf3_lds_jhl") \
-  X(22, 8, 4, 1, true, true, 1, false, true, false, true, 1, "rj8_wj4_wk1_pf1_lds_jhl") \
-  X(23, 8, 4, 2, true, true, 2, false, true, false, true, 1, "rj8_wj4_wk2_pf2_lds_jhl") \
-  X(24, 4, 4, 2, true, true, 4, false, true, false, true, 1, "rj4_wj4_wk2_pf4_lds_jhl") \
-  X(25, 4, 16, 1, true, true, 2, false, true, false, true, 1, "rj4_wj16_wk1_pf2_lds_jhl") \
-  X(26, 2, 16, 1, true, true, 3, false, true, false, true, 1, "rj2_wj16_wk1_pf3_lds_jhl") \
-  X(27, 4, 8, 2, true, true, 2, false, true, false, true, 1, "rj4_wj8_wk2_pf2_lds_jhl") \
-  X(28, 4, 8, 2, true, true, 1, false, true, false, false, 1, "rj4_wj8_wk2_pf1_lds") \
-  X(29, 4, 4, 2, true, true, 2, false, true, false, false, 2, "rj4_wj4_wk2_pf2_lds_kd2") \
-  X(30, 4, 4, 2, true, true, 2, false, true, false, false, 3, "rj4_wj4_wk2_pf2_lds_kd3") \
-  X(31, 8, 4, 2, true, true, 1, false, true, false, false, 2, "rj8_wj4_wk2_pf1_lds_kd2") \
-  X(32, 8, 8, 1, true, true, 1, false, true, false, false, 2, "rj8_wj8_wk1_pf1_lds_kd2") \
-  X(33, 8, 2, 4, true, true, 1, false, true, false, false, 2, "rj8_wj2_wk4_pf1_lds_kd2") \
-  X(34, 4, 16, 1, true, true, 1, false, true, false, false, 2, "rj4_wj16_wk1_pf1_lds_kd2") \
-  X(35, 4, 16, 1, true, true, 1, true, true, false, false, 1, "rj4_wj16_wk1_pf1_lds_ntl")
+  X(8, 4, 4, 1, true, true, 2, false, false, false, false, 1, false, "rj4_wj4_wk1_pf2") \
+  X(9, 4, 4, 1, false, false, 1, false, false, false, false, 1, false, "rj4_wj4_wk1_pf1_shfl_plainst") \
+  X(10, 8, 2, 1, true, true, 1, false, false, false, false, 1, false, "rj8_wj2_wk1_pf1") \
+  X(11, 4, 4, 1, true, true, 1, false, false, false, false, 1, false, "rj4_wj4_wk1_pf1") \
+  X(12, 4, 4, 1, true, true, 2, false, true, false, false, 1, false, "rj4_wj4_wk1_pf2_lds") \
+  X(13, 2, 8, 1, true, true, 4, false, true, false, false, 1, false, "rj2_wj8_wk1_pf4_lds") \
+  X(14, 8, 4, 1, true, true, 1, false, true, false, false, 1, false, "rj8_wj4_wk1_pf1_lds") \
+  X(15, 8, 4, 2, true, true, 1, false, true, false, false, 1, false, "rj8_wj4_wk2_pf1_lds") \
+  X(16, 4, 4, 2, true, true, 3, false, true, false, false, 1, false, "rj4_wj4_wk2_pf3_lds") \
+  X(17, 4, 2, 4, true, true, 2, false, true, false, false, 1, false, "rj4_wj2_wk4_pf2_lds") \
+  X(18, 2, 16, 1, true, true, 3, false, true, false, false, 1, false, "rj2_wj16_wk1_pf3_lds") \
+  X(19, 4, 4, 2, true, true, 2, false, true, false, true, 1, false, "rj4_wj4_wk2_pf2_lds_jhl") \
+  X(20, 4, 8, 1, true, true, 2, false, true, false, true, 1, false, "rj4_wj8_wk1_pf2_lds_jhl") \
+  X(21, 8, 4, 2, true, true, 1, false, true, false, true, 1, false, "rj8_wj4_wk2_pf1_lds_jhl") \
+  X(22, 4, 4, 2, true, true, 3, false, true, false, true, 1, false, "rj4_wj4_wk2_pf3_lds_jhl") \
+  X(23, 8, 4, 1, true, true, 1, false, true, false, true, 1, false, "rj8_wj4_wk1_pf1_lds_jhl") \
+  X(24, 8, 4, 2, true, true, 2, false, true, false, true, 1, false, "rj8_wj4_wk2_pf2_lds_jhl") \
+  X(25, 4, 4, 2, true, true, 4, false, true, false, true, 1, false, "rj4_wj4_wk2_pf4_lds_jhl") \
+  X(26, 4, 16, 1, true, true, 2, false, true, false, true, 1, false, "rj4_wj16_wk1_pf2_lds_jhl") \
+  X(27, 2, 16, 1, true, true, 3, false, true, false, true, 1, false, "rj2_wj16_wk1_pf3_lds_jhl") \
+  X(28, 4, 8, 2, true, true, 2, false, true, false, true, 1, false, "rj4_wj8_wk2_pf2_lds_jhl") \
+  X(29, 4, 8, 2, true, true, 1, false, true, false, false, 1, false, "rj4_wj8_wk2_pf1_lds") \
+  X(30, 4, 4, 2, true, true, 2, false, true, false, false, 2, false, "rj4_wj4_wk2_pf2_lds_kd2") \
+  X(31, 4, 4, 2, true, true, 2, false, true, false, false, 3, false, "rj4_wj4_wk2_pf2_lds_kd3") \
+  X(32, 8, 4, 2, true, true, 1, false, true, false, false, 2, false, "rj8_wj4_wk2_pf1_lds_kd2") \
+  X(33, 8, 8, 1, true, true, 1, false, true, false, false, 2, false, "rj8_wj8_wk1_pf1_lds_kd2") \
+  X(34, 8, 2, 4, true, true, 1, false, true, false, false, 2, false, "rj8_wj2_wk4_pf1_lds_kd2") \
+  X(35, 4, 16, 1, true, true, 1, false, true, false, false, 2, false, "rj4_wj16_wk1_pf1_lds_kd2") \
+  X(36, 4, 16, 1, true, true, 1, true, true, false, false, 1, false, "rj4_wj16_wk1_pf1_lds_ntl") \
+  X(37, 4, 8, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj4_wj8_wk1_pf2") \
+  X(38, 4, 4, 2, true, true, 1, false, true, false, true, 1, true, "pln_rj4_wj4_wk2_pf1") \
+  X(39, 2, 8, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj2_wj8_wk1_pf2") \
+  X(40, 4, 4, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj4_wj4_wk1_pf1") \
+  X(41, 2, 12, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj2_wj12_wk1_pf1")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
-  X(3, 1, 1, 4, true, true, 2, false, false, false, false, 1, "wk4_pf2")  \
-  X(4, 1, 1, 1, true, true, 4, false, false, false, false, 1, "wk1_pf4")  \
-  X(5, 1, 1, 4, true, true, 8, false, false, false, false, 1, "wk4_pf8")  \
-  X(6, 4, 16, 1, true, true, 1, false, true, true, false, 1, "tile_rj4_wj16_wk1")  \
-  X(7, 8, 8, 1, true, true, 1, false, true, true, false, 1, "tile_rj8_wj8_wk1")    \
-  X(8, 2, 16, 1, true, true, 1, false, true, true, false, 1, "tile_rj2_wj16_wk1")  \
-  X(9, 4, 4, 2, true, true, 1, false, true, true, false, 1, "tile_rj4_wj4_wk2")    \
-  X(10, 4, 8, 2, true, true, 1, false, true, true, false, 1, "tile_rj4_wj8_wk2")   \
-  X(11, 8, 4, 1, true, true, 1, false, true, true, false, 1, "tile_rj8_wj4_wk1")   \
-  X(12, 1, 1, 4, false, false, 1, false, false, false, false, 1, "wk4_pf1_shfl_plainst") \
-  X(13, 4, 8, 1, false, false, 1, false, true, true, false, 1, "tile_rj4_wj8_wk1_shfl_plainst")
+  X(3, 1, 1, 4, true, true, 2, false, false, false, false, 1, false, "wk4_pf2")  \
+  X(4, 1, 1, 1, true, true, 4, false, false, false, false, 1, false, "wk1_pf4")  \
+  X(5, 1, 1, 4, true, true, 8, false, false, false, false, 1, false, "wk4_pf8")  \
+  X(6, 4, 16, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj4_wj16_wk1")  \
+  X(7, 8, 8, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj8_wj8_wk1")    \
+  X(8, 2, 16, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj2_wj16_wk1")  \
+  X(9, 4, 4, 2, true, true, 1, false, true, true, false, 1, false, "tile_rj4_wj4_wk2")    \
+  X(10, 4, 8, 2, true, true, 1, false, true, true, false, 1, false, "tile_rj4_wj8_wk2")   \
+  X(11, 8, 4, 1, true, true, 1, false, true, true, false, 1, false, "tile_rj8_wj4_wk1")   \
+  X(12, 1, 1, 4, false, false, 1, false, false, false, false, 1, false, "wk4_pf1_shfl_plainst") \
+  X(13, 4, 8, 1, false, false, 1, false, true, true, false, 1, false, "tile_rj4_wj8_wk1_shfl_plainst")
 #else
 #define NEPTUNE_MARCH3_VARIANTS(X) NEPTUNE_MARCH3_DEFAULT(X)
 #define NEPTUNE_MARCH2_VARIANTS(X) NEPTUNE_MARCH2_DEFAULT(X)
 #endif
 
-#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name},
+#define NEPTUNE_MV_ROW(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name) {RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name},
 constexpr MarchVariant kMarch3[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_ROW)};
 constexpr MarchVariant kMarch2[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_ROW)};
 #undef NEPTUNE_MV_ROW
 // the tables are indexed by position, the launch switch by the X index: they must agree
-#define NEPTUNE_MV_IDX(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) idx,
+#define NEPTUNE_MV_IDX(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name) idx,
 constexpr int kMarch3Idx[] = {NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_IDX)};
 constexpr int kMarch2Idx[] = {NEPTUNE_MARCH2_VARIANTS(NEPTUNE_MV_IDX)};
 #undef NEPTUNE_MV_IDX
@@ -210,18 +218,39 @@ constexpr int kNumMarch2 = sizeof(kMarch2) / sizeof(kMarch2[0]);
 
 // rank 1: a single tile -- the field is one row, a workgroup is 4 waves side by side, every wave
 // loads its 1 KiB, shifts, stores and retires (the access pattern of the fastest copy kernel)
-constexpr MarchVariant kMarch1[] = {{1, 1, 4, true, true, 1, false, false, false, false, 1, "row_wk4"}};
+constexpr MarchVariant kMarch1[] = {{1, 1, 4, true, true, 1, false, false, false, false, 1, false, "row_wk4"}};
 inline int march_variant_count(int rank) { return rank == 3 ? kNumMarch3 : (rank == 2 ? kNumMarch2 : (rank == 1 ? 1 : 0)); }
 inline const MarchVariant* march_variant(int rank, int v) {
   if (v < 0 || v >= march_variant_count(rank)) return nullptr;
   return rank == 3 ? &kMarch3[v] : (rank == 2 ? &kMarch2[v] : &kMarch1[v]);
 }
 
+// ragged rows: a stored cell's K neighbours must come from lanes that hold real cells, so a K radius of n lane vectors
+// leaves n-1 more vectors per row to the tail launch
+template <class FP, int VK>
+constexpr int ragged_extra_vectors() { return FP::R2 > VK ? (FP::R2 + VK - 1) / VK - 1 : 0; }
+
 // rows per lane a tile really gets for a footprint: rank-3 footprints with wide register state (boxes, radius 2 and
 // more, several halo inputs) are capped at 4 -- on the 8-row tiles they would only spill
 template <class FP, int RANK>
 constexpr int march_rows(int rj) {
   return (RANK == 3 && rj > 4 && (FP::BOX || FP::R0 > 1 || FP::R1 > 1 || popcount_u(FP::HALO_MASK) > 1)) ? 4 : rj;
+}
+
+// the tile a table row becomes for a footprint: PLN rows run the plane kernel where it can (with the rows per lane its ring
+// leaves room for) and fall back to the same shape of the march kernel elsewhere; footprints only the plane kernel can
+// hold (radius beyond 4) run it on EVERY row
+template <class FP, int RANK>
+constexpr bool plane_only() { return plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4); }
+template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT, int PF, bool NTL, bool LDSJ, bool JK, bool JHL, int KD, bool PLN>
+struct TileFor {
+  static constexpr bool pln = plane_capable<FP, RANK>() && (PLN || plane_only<FP, RANK>());
+  using type = Tile<pln ? plane_rows<T, FP>(RJ, WJ, WK) : march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>;
+};
+template <class Body, class T, int RANK, int NIN, class FP, class TL>
+constexpr auto march_kernel_fn() {
+  if constexpr (TL::PLN) return &neptune_apply_plane<Body, T, NIN, FP, TL>;
+  else return &neptune_apply_march<Body, T, RANK, NIN, FP, TL>;
 }
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
@@ -232,7 +261,7 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   const int64_t tileK = (int64_t)WK * kWave * VK, tileJ = (int64_t)WJ * RJ;
   P.Kl = P.N2 / VK * VK - VK;
   // a K radius beyond one vector reads two lanes to the right: leave one more vector of ragged rows to the tail
-  P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl - (FP::R2 > VK ? VK : 0);
+  P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl - ragged_extra_vectors<FP, VK>() * VK;
   P.nK = (uint32_t)((P.Ks + tileK - 1) / tileK);
   P.nJ = (uint32_t)((P.rJ1 - P.rJ0 + tileJ - 1) / tileJ);
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
@@ -248,7 +277,7 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
       int dev = 0, cus = 256, per_cu = 1;
       hipDeviceProp_t prop;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, neptune_apply_march<Body, T, RANK, NIN, FP, TL>,
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, march_kernel_fn<Body, T, RANK, NIN, FP, TL>(),
                                                        kWave * WJ * WK, 0) != hipSuccess || per_cu < 1)
         per_cu = 1;
       (void)hipGetLastError();
@@ -275,7 +304,8 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
     abort();
   }
   P.chunk = (int32_t)chunk;
-  hipLaunchKernelGGL((neptune_apply_march<Body, T, RANK, NIN, FP, TL>), dim3((uint32_t)blocks),
+  const auto kern = march_kernel_fn<Body, T, RANK, NIN, FP, TL>();
+  hipLaunchKernelGGL(kern, dim3((uint32_t)blocks),
                      dim3(kWave * WJ * WK), 0, stream, P, body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
 }
@@ -285,10 +315,10 @@ inline void launch_march(int variant, MarchParams<T, NIN>& P, const Body& body, 
                          hipStream_t stream) {
   // footprints with wide register state (boxes, radius 2+, several halo inputs) cap the rows per lane at 4: on an
   // 8-row tile they would only spill (kMarchRowCap)
-#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name)                             \
+#define NEPTUNE_MV_CASE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name)                        \
   case idx:                                                                                                     \
     launch_march_variant<Body, T, RANK, NIN, FP,                                                                \
-                         Tile<march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD>>( \
+                         typename TileFor<T, FP, RANK, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN>::type>( \
         P, body, planes, chunk, stream);                                                                        \
     break;
   if constexpr (RANK == 3) {
@@ -320,7 +350,7 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
   const int64_t nK = g->out_ub[RANK - 1] - g->out_lb[RANK - 1];
   // ragged rows (nK % VK != 0): the kernel stores all whole vectors but the last, the rest of each row
   // goes to a direct-kernel launch (launch_apply below)
-  const int64_t nK_march = (nK % VK == 0) ? nK : nK / VK * VK - VK - (FP::R2 > VK ? VK : 0);
+  const int64_t nK_march = (nK % VK == 0) ? nK : nK / VK * VK - VK - ragged_extra_vectors<FP, VK>() * VK;
   ok = ok && nK_march >= VK;
   {
     // in-plane offsets are 32-bit in the march kernel: every extent and one plane's bytes
@@ -384,7 +414,9 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     // (2-D stars of radius 3-4 march down the rows like many-input applies: 8192^2 radius 4 measured 4.55 TB/s
     // against 3.2 on the tile form, whose row halo then is as tall as the tile; likewise the 25-point 5x5 box: 3.3
     // against 2.4)
-    variant = RANK == 3 ? (kWideState ? (FP::R0 > 3 ? 5 : 2) : FP::BOX ? 1 : 0)
+    // high-order 3-D stars (radius 3 and more): the plane-in-LDS kernel, four own rows per lane instead of two
+    constexpr bool kPlane = plane_capable<FP, RANK>() && (FP::R0 > 2 || FP::R1 > 2 || FP::R2 > 2);
+    variant = RANK == 3 ? (kPlane ? 7 : kWideState ? (FP::R0 > 3 ? 5 : 2) : FP::BOX ? 1 : 0)
                         : (RANK == 2 && (kNH > 2 || FP::R0 > 2 || (FP::BOX && FP::R0 > 1))) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {
       // rows that fill the two-wave-wide tile badly (320 or 384 f64 cells against 256-cell tiles: a quarter to a
@@ -439,8 +471,8 @@ inline int march3_variant_scratch(int variant) {
     auto it = cache.find(variant);
     if (it != cache.end()) return it->second;
     const void* fn = nullptr;
-#define NEPTUNE_MV_FN(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, name) \
-  case idx: fn = (const void*)neptune_apply_march<Body, T, RANK, NIN, FP, Tile<march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, false, JHL, KD>>; break;
+#define NEPTUNE_MV_FN(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name) \
+  case idx: fn = (const void*)march_kernel_fn<Body, T, RANK, NIN, FP, typename TileFor<T, FP, RANK, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, false, JHL, KD, PLN>::type>(); break;
     switch (variant) { NEPTUNE_MARCH3_VARIANTS(NEPTUNE_MV_FN) default: break; }
 #undef NEPTUNE_MV_FN
     int bytes = -1;

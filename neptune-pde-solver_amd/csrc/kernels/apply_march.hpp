@@ -192,11 +192,13 @@ struct MarchAcc {
 //         same step as the rows of the same plane (KD = R0 + PF) the two requests for one line fall close together in
 //         time whichever workgroup is ahead, and the later one finds the line in the XCD's L2; requested a step later
 //         (KD = 1) the line has often been evicted again (an XCD streams ~5 MiB per plane step through its 4 MiB L2).
+//   PLN   run the plane-in-LDS kernel (apply_plane.hpp) instead of this one: rank-3 stars, J and K neighbours read from the
+//         centre plane laid out in LDS; only RJ, WJ, WK, PF and NT mean anything there
 template <int RJ_, int WJ_, int WK_, bool DPP_, bool NT_, int PF_, bool NTL_, bool LDSJ_ = false, bool JK2_ = false,
-          bool JHL_ = false, int KD_ = 1>
+          bool JHL_ = false, int KD_ = 1, bool PLN_ = false>
 struct Tile {
   static constexpr int RJ = RJ_, WJ = WJ_, WK = WK_, PF = PF_, KD = KD_;
-  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_, JHL = JHL_;
+  static constexpr bool DPP = DPP_, NT = NT_, NTL = NTL_, LDSJ = LDSJ_, JK2 = JK2_, JHL = JHL_, PLN = PLN_;
 };
 
 template <class Body, class T, int RANK, int NIN, class FP, class TL>

@@ -1,0 +1,304 @@
+// apply_plane.hpp -- rank-3 STAR stencils of any radius: the march kernel's traversal with the centre plane's
+// neighbourhood in LDS instead of registers.
+//
+// A star reads its I neighbours (dim 0) on the cell's own (row, column) and its J / K neighbours on the centre plane only.
+// The march kernel (apply_march.hpp) serves the J / K neighbours from registers: halo rows exchanged through LDS INTO
+// registers, K neighbours by wave shifts with scalar halo cells.  For a 7-point stencil that is the cheapest form; for the
+// high-order operators (radius 3-4: 19- and 25-point, the seismic stencils) the 2*R1 halo rows per lane, their in-flight
+// copies and 2*R2 scalar halo cells per row leave room for TWO own rows per lane next to the 2*R0+1 ring planes -- 16 KiB
+// of row loads in flight per CU, and the kernel is latency-bound at a third of the HBM rate (profiles/r01_highorder.txt).
+//
+// Here the registers hold nothing but the ring of the lane's OWN cells (2*R0+1 planes x RJ rows x 16 B) and the planes in
+// flight.  Every step the workgroup lays the plane that has just become the centre out in LDS -- its own rows, the R1
+// rows above and below its window and the R2 cells left and right of it -- and the body reads J and K neighbours straight
+// from there (ds_read with compile-time offsets; nothing staged in registers, no wave shifts, no scalar halo cells).
+// That frees the registers for FOUR own rows per lane at radius 4 and makes every radius up to 8 fit (RJ = 2).
+//
+//   * window    : WJ x WK waves, RJ rows x 64 lane vectors each; LDS holds [2][WJ*RJ + 2*R1][WK*64*VK + 2*HK] cells
+//                 (double-buffered by step parity: ONE barrier per plane step).
+//   * halo rows : the 2*R1 rows outside the window are dealt over the workgroup's waves (one 16-byte row load per wave and
+//                 step for radius 4 on the 8-wave tile) and requested PF steps before their plane becomes the centre -- by
+//                 then the neighbouring workgroup has pulled them through the XCD's L2 as its own rows.
+//   * halo cells: the R2 cells beside the window's rows: one element load per row by the first 2*HK lanes of the
+//                 window's outermost waves (clamped per cell, so ragged rows need nothing special).
+//   * everything else (tile numbering, chunks of planes, clamped addresses, predicated non-temporal stores, copy-through
+//     and bounds test folded into the store, ragged rows) is the march kernel's; it shares MarchParams and the launcher.
+//
+// Same semantics as the reference's loop nest (lib/Passes/DataflowLowering.cpp:258-448), same bits as the other kernels.
+#pragma once
+#include "apply_march.hpp"
+
+namespace neptune_hip {
+
+// can the plane kernel run this footprint?  rank 3, one halo input, star, radii that leave a window in LDS
+template <class FP, int RANK>
+constexpr bool plane_capable() {
+  return RANK == 3 && FP::MARCH_OK && !FP::BOX && popcount_u(FP::HALO_MASK) == 1 && (FP::R1 > 0 || FP::R2 > 0) && FP::R0 <= 8 &&
+         FP::R1 <= 8 && FP::R2 <= 8;
+}
+// rows per lane the plane kernel gives a footprint on a WJ x WK window: the ring is (2*R0+1) * RJ * 4 VGPRs (kept below
+// ~150 of the 256 a wave has at two waves per SIMD), and the double-buffered window must fit the CU's 160 KiB of LDS
+template <class T, class FP>
+constexpr int plane_rows(int rj, int wj, int wk) {
+  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK;
+  while (rj > 1 && (2 * FP::R0 + 1) * rj * 4 > 150) rj /= 2;
+  while (rj > 1 && 2 * (wj * rj + 2 * FP::R1) * (wk * kWave * VK + 2 * HK) * (int)sizeof(T) > 160 * 1024) rj /= 2;
+  return rj;
+}
+
+// PH / NS / RR: the ring is addressed in place -- plane offset oi of the current step lives in slot (PH + oi + RR) mod NS
+// (RR: planes the ring keeps on each side of the centre, max(R0, 1))
+template <class T, int NIN, class FP, int RJ, int r, int e, int LROW, int PH, int NS, int RR>
+struct PlaneAcc {
+  static constexpr int VK = 16 / sizeof(T);
+  static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, NP = 2 * R0 + 1;
+  static constexpr unsigned HMASK = FP::HALO_MASK;
+  using V = typename Vec16<T>::type;
+
+  const V (&ring)[NS][RJ];
+  const V (&pt)[NIN][RJ];
+  const T* lp;         // LDS: this lane's cell (own row 0, element 0) of the centre plane
+  int64_t li, lj, lk;  // logical coordinates
+
+  template <int IN, int... O>
+  __device__ __forceinline__ T get() const {
+    static_assert(IN >= 0 && IN < NIN, "input index out of range");
+    constexpr int oi = PickOffset<3, 0, O...>::value, oj = PickOffset<3, 1, O...>::value, ok = PickOffset<3, 2, O...>::value;
+    if constexpr ((HMASK >> IN) & 1u) {
+      static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2, "access outside the declared footprint");
+      static_assert((oi != 0) + (oj != 0) + (ok != 0) <= 1, "star footprint declared but a diagonal access is used");
+      // I neighbours and the J neighbours that are own rows of this lane sit in the ring; the rest is read from LDS
+      if constexpr (ok == 0 && r + oj >= 0 && r + oj < RJ) return ring[(PH + oi + RR) % NS][r + oj][e];
+      else return lp[(r + oj) * LROW + e + ok];
+    } else {
+      static_assert(oi == 0 && oj == 0 && ok == 0, "only halo inputs may be read at an offset");
+      return pt[IN][r][e];
+    }
+  }
+  template <int D>
+  __device__ __forceinline__ int64_t idx() const {
+    static_assert(D >= 0 && D < 3, "index argument out of range");
+    return D == 0 ? li : (D == 1 ? lj : lk);
+  }
+};
+
+// TL: a march Tile (RJ, WJ, WK, PF, NT are used)
+template <class Body, class T, int NIN, class FP, class TL>
+__global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(MarchParams<T, NIN> P, Body body) {
+  constexpr int RJ = TL::RJ, WJ = TL::WJ, WK = TL::WK, PF = TL::PF, NW = WJ * WK;
+  constexpr bool NT = TL::NT;
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, NP = 2 * R0 + 1;
+  constexpr unsigned HMASK = FP::HALO_MASK;
+  static_assert(popcount_u(HMASK) == 1 && !FP::BOX, "plane kernel: one halo input, star footprint");
+  constexpr int HIN = halo_input_of(HMASK, 0);
+  constexpr int HK = (R2 + VK - 1) / VK * VK;  // halo cells kept per side (whole lane vectors keep own cells 16-byte aligned)
+  constexpr int TJ = WJ * RJ, SPAN = kWave * VK, TK = WK * SPAN;
+  constexpr int LROW = TK + 2 * HK, LR = TJ + 2 * R1;
+  constexpr int NU = 2 * R1 * WK;              // halo-row units (one row x one wave span), dealt over the waves
+  constexpr int NHW = NU ? (NU + NW - 1) / NW : 0, NHWX = NHW ? NHW : 1;
+  static_assert(2 * HK <= kWave, "K halo cells are loaded by the first 2*HK lanes");
+  static_assert(2 * LR * LROW * (int)sizeof(T) <= 160 * 1024, "window does not fit the LDS");
+  __shared__ __attribute__((aligned(16))) T lds[2][LR][LROW];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wj = w / WK, wk = w % WK;
+
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = v % P.nK;
+  const uint32_t t = v / P.nK;
+  const uint32_t jt = t % P.nJ;
+  const uint32_t ct = t / P.nJ;
+
+  const int32_t j0w = P.rJ0 + (int32_t)(jt * TJ);   // the window's first row
+  const int32_t j0 = j0w + wj * RJ;                 // first own row
+  const int32_t kw0 = (int32_t)(kt * (uint32_t)TK);  // the window's first column
+  const int32_t kw = kw0 + wk * SPAN;
+  const int32_t k0 = kw + lane * VK;
+  const bool lane_ok = k0 < P.Ks;
+  const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
+
+  const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
+  const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
+  if (ib >= ie) return;
+  const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
+
+  auto row_bytes = [&](int32_t j) -> uint32_t {
+    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  };
+  uint32_t rowb[RJ];
+  static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[r] = row_bytes(j0 + r); });
+
+  // halo-row units of this wave: unit u = w + t*NW -> halo row x = u / WK (x < R1: above the window), wave span u % WK
+  uint32_t hsrc[NHWX];   // byte offset within a plane of my 16 bytes of the unit
+  int32_t hdst[NHWX];    // LDS cell index (within one buffer) they go to; -1: no unit
+  static_for<NHW>([&](auto tc) {
+    constexpr int tt = tc;
+    const int u = w + tt * NW;
+    const int x = u / WK, s = u % WK;
+    const int32_t kc = kw0 + s * SPAN + lane * VK;
+    hsrc[tt] = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1)) + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T);
+    hdst[tt] = u < NU ? (x < R1 ? x : TJ + x) * LROW + HK + s * SPAN + lane * VK : -1;
+  });
+  // halo cells beside my own rows: lanes [0,HK) the cells left of the window (its leftmost waves), lanes [HK,2HK) the
+  // cells right of it (its rightmost waves); clamped per cell
+  const bool kh_left = R2 > 0 && wk == 0 && lane < HK, kh_right = R2 > 0 && wk == WK - 1 && lane >= HK && lane < 2 * HK;
+  const bool kh_any = kh_left || kh_right;
+  int32_t khc = kh_left ? kw0 - HK + lane : kw0 + TK + (lane - HK);
+  khc = khc < 0 ? 0 : (khc >= P.N2 ? P.N2 - 1 : khc);
+  const uint32_t kh_b = (uint32_t)khc * (uint32_t)sizeof(T);
+  const int32_t kh_dst = (R1 + wj * RJ) * LROW + (kh_left ? lane : HK + TK + (lane - HK));
+
+  // ---- register state: the ring of own cells with the planes in flight, the halo pieces in flight ----
+  // The ring keeps RR = max(R0, 1) planes on each side of the centre (the plane AFTER the centre is laid out in LDS one
+  // step ahead, so it must have arrived even when the body reads no I neighbour) plus the PF planes in flight: NS slots.
+  // PHASED: the ring is never moved -- the step loop is unrolled NS times and step phase ph finds plane offset oi in slot
+  // (ph + oi + RR) mod NS; the load of plane i+RR+PF goes straight into the slot of the plane that has just left the
+  // stencil's reach.  (Rotating the ring costs (NP-1)*RJ 16-byte moves per step: 17 % of the vector instructions of a
+  // radius-4 step.)  Long rings keep the rotation: NS copies of the step would not fit the instruction cache.  Slots
+  // NP.. are the planes in flight then.
+  constexpr int RR = R0 > 1 ? R0 : 1, NPR = 2 * RR + 1;
+  constexpr int NS = NPR + PF;
+  constexpr bool PHASED = NS <= 10;
+  constexpr int UNROLL = PHASED ? NS : PF;
+  V ring[NS][RJ];
+  V jh[NHWX];   // my halo-row units and halo cells of the plane after next's centre... of plane i+2 while step i computes
+  T kh[RJ];
+  V pt[NIN][RJ], npt[NIN][RJ];
+
+  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
+    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
+  };
+  auto load_rows = [&](int32_t ip, V(&rows)[RJ]) {
+    const char* base = plane_base(P.in[HIN], ip);
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; rows[r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+  };
+  auto load_halos = [&](int32_t ip, V(&hrows)[NHWX], T(&hcells)[RJ]) {
+    const char* base = plane_base(P.in[HIN], ip);
+    static_for<NHW>([&](auto tc) {
+      constexpr int tt = tc;
+      if (hdst[tt] >= 0) hrows[tt] = *reinterpret_cast<const V*>(base + hsrc[tt]);
+    });
+    if constexpr (R2 > 0) {
+      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; hcells[r] = *reinterpret_cast<const T*>(base + (rowb[r] + kh_b)); });
+    }
+  };
+  auto load_point_inputs = [&](int32_t ip, V(&dst)[NIN][RJ]) {
+    static_for<NIN>([&](auto nc) {
+      constexpr int n = nc;
+      if constexpr (n != HIN) {
+        const char* base = plane_base(P.in[n], ip);
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; dst[n][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+      }
+    });
+  };
+
+  bool in_j[RJ], row_ok[RJ], in_k[VK];
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    in_j[r] = (j0 + r) >= P.plb[1] && (j0 + r) < P.pub[1];
+    row_ok[r] = (j0 + r) < P.rJ1;
+  });
+  static_for<VK>([&](auto ec) {
+    constexpr int e = ec;
+    in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
+  });
+
+  const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;  // my cell (own row 0, element 0) in a buffer
+  // lay a plane out in LDS buffer `b`: my own rows (from the ring), my halo-row units, the halo cells beside my rows
+  auto lay_out = [&](int b, const V(&rows)[RJ]) {
+    T* buf = &lds[b][0][0];
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + own_cell + r * LROW) = rows[r]; });
+    static_for<NHW>([&](auto tc) {
+      constexpr int tt = tc;
+      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[tt];
+    });
+    if constexpr (R2 > 0) {
+      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; buf[kh_dst + r * LROW] = kh[r]; });
+    }
+  };
+
+  // ---- prologue: planes ib-RR .. ib+RR+PF-1 (the last PF of them stay in flight); plane ib laid out in buffer 0, the
+  // halos of plane ib+1 in flight
+  load_halos(ib, jh, kh);
+  static_for<NS - 1>([&](auto pc) {
+    constexpr int p = pc;
+    // phased: plane ib-RR+p -> slot p.  rotating: slots 1.. (shifted down at the top of the first step)
+    load_rows(ib - RR + p, ring[PHASED ? p : p + 1]);
+  });
+  load_point_inputs(ib, npt);
+  lay_out(0, ring[PHASED ? RR : RR + 1]);
+  load_halos(ib + 1, jh, kh);
+
+  // One plane step.  Order: barrier (buffer i&1 is complete, the other one free) -> lay plane i+1 out in the other buffer
+  // (its halos were requested a step ago) -> request the halos of plane i+2 and the rows of plane i+RR+PF -> compute
+  // plane i from buffer i&1.  The LDS writes and every load thus have a whole compute phase to complete in.
+  auto step = [&](const int32_t i, auto phase_c) {
+    constexpr int ph = PHASED ? decltype(phase_c)::value : 0;   // ring phase
+    constexpr int slot = decltype(phase_c)::value % PF;
+    constexpr int CS = (ph + RR) % NS;                            // slot of the centre plane
+    if constexpr (!PHASED) {
+      static_for<NPR - 1>([&](auto pc) {
+        constexpr int p = pc;
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[p][r] = ring[p + 1][r]; });
+      });
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[NPR - 1][r] = ring[NPR + slot][r]; });
+    }
+    static_for<NIN>([&](auto nc) {
+      constexpr int n = nc;
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = npt[n][r]; });
+    });
+
+    __syncthreads();
+    // no "is that plane still in my chunk?" tests here: plane indices are clamped into the field, so the few loads past
+    // the chunk's end are harmless, and straight-line code lets the compiler count its waits exactly (with the tests it
+    // drained vmcnt to zero at the top of every step)
+    lay_out((i + 1 - ib) & 1, ring[(CS + 1) % NS]);
+    load_halos(i + 2, jh, kh);
+    load_rows(i + PF + RR, ring[PHASED ? (ph + NS - 1) % NS : NPR + slot]);
+    load_point_inputs(i + 1, npt);
+
+    const bool in_i = i >= P.plb[0] && i < P.pub[0];
+    const int64_t li = (int64_t)i + P.olb[0];
+    char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
+    const T* lp = &lds[(i - ib) & 1][0][0] + own_cell;
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      const int64_t lj = (int64_t)(j0 + r) + P.olb[1];
+      const bool in_ij = in_i && in_j[r];
+      V res;
+      static_for<VK>([&](auto ec) {
+        constexpr int e = ec;
+        const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
+        const bool inside = in_ij && in_k[e];
+        PlaneAcc<T, NIN, FP, RJ, r, e, LROW, ph, NS, RR> acc{ring, pt, lp, li, lj, lk};
+        const T val = body(acc);
+        T through;
+        if constexpr (HMASK & 1u) through = ring[CS][r][e];
+        else through = pt[0][r][e];
+        res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
+      });
+      if (row_ok[r] && lane_ok) {
+        V* dst = reinterpret_cast<V*>(obase + (rowb[r] + lane_b));
+        if constexpr (NT) __builtin_nontemporal_store(res, dst);
+        else *dst = res;
+      }
+      // one row at a time: without the fence the scheduler hoists every row's LDS reads to the top of the step and the
+      // 2*(R1+R2) neighbour vectors of ALL rows are live at once (radius 4: 120 VGPRs, spills)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  for (int32_t i = ib; i < ie; i += UNROLL) {
+    static_for<UNROLL>([&](auto phc) {
+      constexpr int ph = phc;
+      if (i + ph < ie) step(i + ph, phc);
+    });
+  }
+}
+
+}  // namespace neptune_hip

@@ -301,6 +301,9 @@ struct Emitter {
     const int rbig = std::max(R[0], std::max(R[1], R[2]));
     const int hmax = rank == 3 ? (rbig > 1 ? 1 : 2) : ((rbig > 2 || (fp.box && rbig > 1)) ? 1 : 4);
     fp.march_ok = fp.halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= (rank == 3 ? rmax : 2 * vk) && R[2] <= 2 * vk;
+    // 3-D stars of one halo input beyond that, up to radius 8 (10th- to 16th-order operators): the plane-in-LDS kernel
+    // (apply_plane.hpp) keeps only the ring of own cells in registers and reads J / K neighbours from the centre plane in LDS
+    if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs == 1 && rbig <= 8) fp.march_ok = true;
     if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }
     return true;
   }

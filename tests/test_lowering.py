@@ -253,7 +253,8 @@ def test_several_halo_inputs_get_a_mask_and_shared_radii():
 
 
 def test_footprint_limits_of_the_march_kernel():
-    """which footprints the emitter hands to the march kernel (emit_hip.cpp analyze_apply): stars up to radius 4, a K
+    """which footprints the emitter hands to the march kernel (emit_hip.cpp analyze_apply): stars up to radius 4 (3-D stars
+    of one halo input up to radius 8: plane-in-LDS kernel), in 1-D / 2-D a K
     radius of at most two 16-byte lane vectors, 3-D boxes of radius 1, 2-D boxes of radius 2, one wide halo input;
     every test_multihalo_gpu case is listed with the kernel it expects"""
     import test_multihalo_gpu as mh
@@ -269,7 +270,14 @@ def test_footprint_limits_of_the_march_kernel():
 
     k, src = kernel_of((20, 20, 128), "f32", [(0, o) for o in mh.star(3, 4)], 4)
     assert k == "march" and "neptune_hip::Footprint<0, 4, 4, 4, false, true>" in src
-    assert kernel_of((24, 24, 128), "f32", [(0, o) for o in mh.star(3, 5) if max(map(abs, o)) in (0, 5)], 5)[0] == "direct"
+    # 3-D stars of one halo input reach radius 8 (the plane-in-LDS kernel holds only the ring of own cells in registers)
+    k, src = kernel_of((24, 24, 128), "f32", [(0, o) for o in mh.star(3, 5) if max(map(abs, o)) in (0, 5)], 5)
+    assert k == "march" and "neptune_hip::Footprint<0, 5, 5, 5, false, true>" in src
+    assert kernel_of((40, 40, 128), "f64", [(0, o) for o in mh.star(3, 8)], 8)[0] == "march"
+    assert kernel_of((40, 40, 128), "f64", [(0, o) for o in mh.star(3, 9) if max(map(abs, o)) in (0, 9)], 9)[0] == "direct"
+    two = [(0, o) for o in mh.star(3, 5)] + [(1, o) for o in mh.star(3, 1)[1:]]
+    src, rep = lowering.to_hip(mh.module_text((24, 24, 128), "f64", 2, two, [5] * 3, [19] * 3))
+    assert rep["applies"][0]["kernel"] == "direct"                  # two halo inputs beyond radius 1: direct
     # 1-D: the K radius may reach two lane vectors (8 f32 cells, 4 f64 cells)
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 8)], 8)[0] == "march"
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 9)], 9)[0] == "direct"

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 # exactly representable, all different, so a swapped operand or ring slot changes bits
 COEF = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 0.0625, -3.0, 1.75, 0.3125, -0.4375, 2.5, -0.1875, 0.875,
         1.125, -2.25, 0.6875, -0.5625, 3.5, -1.375, 0.21875, 0.9375, -1.625, 2.75, -0.3125, 1.0625]
+COEF = COEF + [c * 0.5 + 0.03125 for c in COEF]   # 49 taps for a radius-8 star: dyadic, so every product stays exact-ish and distinct
 
 
 def module_text(shape, elem, nin, accesses, lb, ub):
@@ -120,6 +121,19 @@ CASES = {
     "radius4_3d": ((12, 14, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "march"),
     "radius4_3d_f32": ((13, 12, 260), "f32", 1, [(0, o) for o in star(3, 4)], 4, "march"),
     "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "direct"),
+    # the plane-in-LDS kernel (apply_plane.hpp): 3-D stars of one halo input, radius 3-4 by default and up to radius 8 on
+    # every tile (beyond radius 4 nothing else holds the ring); a second input read at the centre (leapfrog schemes);
+    # unequal radii per axis; a window two waves wide is reached through the full variant list only
+    "radius5_3d": ((15, 41, 256), "f64", 1, [(0, o) for o in star(3, 5)], 5, "march"),
+    "radius6_3d_f32_ragged": ((17, 37, 263), "f32", 1, [(0, o) for o in star(3, 6)], 6, "march"),
+    "radius8_3d": ((21, 23, 130), "f64", 1, [(0, o) for o in star(3, 8)], 8, "march"),
+    "radius8_3d_f32": ((20, 22, 512), "f32", 1, [(0, o) for o in star(3, 8) if o[2] % 3 != 1], 8, "march"),
+    "radius4_3d_leapfrog": ((12, 35, 256), "f64", 2, [(0, o) for o in star(3, 4)] + [(1, (0, 0, 0))], 4, "march"),
+    "radius4_3d_point0": ((13, 14, 128), "f64", 2, [(0, (0, 0, 0))] + [(1, o) for o in star(3, 4)], 4, "march"),
+    "unequal_radii_3d": ((11, 30, 256), "f64", 1,
+                         [(0, (0, 0, 0)), (0, (-2, 0, 0)), (0, (1, 0, 0)), (0, (0, -5, 0)), (0, (0, 3, 0)), (0, (0, 0, 1)), (0, (0, 0, -3))],
+                         5, "march"),
+    "radius3_jk_only_3d": ((7, 21, 384), "f32", 1, [(0, o) for o in star(3, 3) if o[0] == 0], 3, "march"),
 }
 
 
@@ -164,7 +178,7 @@ def test_several_halo_inputs_match_the_oracle(env, launch_env, name):
     # automatic tile, then every default tile with chunk seams inside the field, then the direct kernel
     settings = [{}]
     if kernel == "march":
-        nvar = {3: 7, 2: 3, 1: 1}[rank]
+        nvar = {3: 8, 2: 3, 1: 1}[rank]
         settings += [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c} for v in range(nvar) for c in ("1", "4")]
         settings += [{"NEPTUNE_HIP_KERNEL": "direct"}]
     for s in settings:
