@@ -414,8 +414,10 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     // (2-D stars of radius 3-4 march down the rows like many-input applies: 8192^2 radius 4 measured 4.55 TB/s
     // against 3.2 on the tile form, whose row halo then is as tall as the tile; likewise the 25-point 5x5 box: 3.3
     // against 2.4)
-    // high-order 3-D stars (radius 3 and more): the plane-in-LDS kernel, four own rows per lane instead of two
-    constexpr bool kPlane = plane_capable<FP, RANK>() && (FP::R0 > 2 || FP::R1 > 2 || FP::R2 > 2);
+    // 3-D stars of radius 2 and more (13-, 19-, 25-point operators ...): the plane-in-LDS kernel, four own rows per lane
+    // (512^3 fp64: radius 2 4.96 TB/s against 4.53 on tile 2, radius 3 4.6 against 3.6, radius 4 4.1 against 2.8 on tile 5;
+    // profiles/r02_plane.txt)
+    constexpr bool kPlane = plane_capable<FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1);
     variant = RANK == 3 ? (kPlane ? 7 : kWideState ? (FP::R0 > 3 ? 5 : 2) : FP::BOX ? 1 : 0)
                         : (RANK == 2 && (kNH > 2 || FP::R0 > 2 || (FP::BOX && FP::R0 > 1))) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   V ring[NS][RJ];
   V jh[NHWX];   // my halo-row units and halo cells of the plane after next's centre... of plane i+2 while step i computes
   T kh[RJ];
-  V pt[NIN][RJ], npt[NIN][RJ];
+  V pt[NIN][RJ];   // inputs read at the centre only: row r of the next plane is requested as soon as row r has been computed
 
   auto plane_base = [&](const T* field, int32_t ip) -> const char* {
     const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
@@ -187,13 +187,11 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
       if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; hcells[r] = *reinterpret_cast<const T*>(base + (rowb[r] + kh_b)); });
     }
   };
-  auto load_point_inputs = [&](int32_t ip, V(&dst)[NIN][RJ]) {
+  auto load_point_row = [&](int32_t ip, auto rc) {
+    constexpr int r = decltype(rc)::value;
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
-      if constexpr (n != HIN) {
-        const char* base = plane_base(P.in[n], ip);
-        static_for<RJ>([&](auto rc) { constexpr int r = rc; dst[n][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
-      }
+      if constexpr (n != HIN) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
     });
   };
 
@@ -230,7 +228,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     // phased: plane ib-RR+p -> slot p.  rotating: slots 1.. (shifted down at the top of the first step)
     load_rows(ib - RR + p, ring[PHASED ? p : p + 1]);
   });
-  load_point_inputs(ib, npt);
+  static_for<RJ>([&](auto rc) { load_point_row(ib, rc); });
   lay_out(0, ring[PHASED ? RR : RR + 1]);
   load_halos(ib + 1, jh, kh);
 
@@ -248,10 +246,6 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
       });
       static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[NPR - 1][r] = ring[NPR + slot][r]; });
     }
-    static_for<NIN>([&](auto nc) {
-      constexpr int n = nc;
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = npt[n][r]; });
-    });
 
     __syncthreads();
     // no "is that plane still in my chunk?" tests here: plane indices are clamped into the field, so the few loads past
@@ -260,7 +254,6 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     lay_out((i + 1 - ib) & 1, ring[(CS + 1) % NS]);
     load_halos(i + 2, jh, kh);
     load_rows(i + PF + RR, ring[PHASED ? (ph + NS - 1) % NS : NPR + slot]);
-    load_point_inputs(i + 1, npt);
 
     const bool in_i = i >= P.plb[0] && i < P.pub[0];
     const int64_t li = (int64_t)i + P.olb[0];
@@ -287,6 +280,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }
+      if constexpr (NIN > 1) load_point_row(i + 1, rc);
       // one row at a time: without the fence the scheduler hoists every row's LDS reads to the top of the step and the
       // 2*(R1+R2) neighbour vectors of ALL rows are live at once (radius 4: 120 VGPRs, spills)
       __builtin_amdgcn_sched_barrier(0);

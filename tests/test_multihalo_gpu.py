@@ -124,6 +124,7 @@ CASES = {
     # the plane-in-LDS kernel (apply_plane.hpp): 3-D stars of one halo input, radius 3-4 by default and up to radius 8 on
     # every tile (beyond radius 4 nothing else holds the ring); a second input read at the centre (leapfrog schemes);
     # unequal radii per axis; a window two waves wide is reached through the full variant list only
+    "radius2_3d": ((10, 21, 256), "f64", 1, [(0, o) for o in star(3, 2)], 2, "march"),
     "radius5_3d": ((15, 41, 256), "f64", 1, [(0, o) for o in star(3, 5)], 5, "march"),
     "radius6_3d_f32_ragged": ((17, 37, 263), "f32", 1, [(0, o) for o in star(3, 6)], 6, "march"),
     "radius8_3d": ((21, 23, 130), "f64", 1, [(0, o) for o in star(3, 8)], 8, "march"),
