@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmcm_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/raw" -- python3 "$ROOT/tools/time_module.py" "$@" > "$OUT/time.json" 2> "$OUT/err.txt" || { tail -20 "$OUT/err.txt"; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/raw" -- python3 "$ROOT/tools/time_module.py" "$@" > "$OUT/time.json" 2> "$OUT/err.txt" || { tail -20 "$OUT/err.txt"; exit 1; }
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"
 import csv, glob, os, sys, collections
 out = sys.argv[1]
