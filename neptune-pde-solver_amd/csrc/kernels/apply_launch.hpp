@@ -240,16 +240,23 @@ constexpr int march_rows(int rj) {
 // the tile a table row becomes for a footprint: PLN rows run the plane kernel where it can (with the rows per lane its ring
 // leaves room for) and fall back to the same shape of the march kernel elsewhere; footprints only the plane kernel can
 // hold (radius beyond 4) run it on EVERY row
-template <class FP, int RANK>
-constexpr bool plane_only() { return plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4); }
+template <class T, class FP, int RANK>
+constexpr bool plane_only() {
+  return (plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4)) ||
+         (planes_capable<T, FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1));
+}
 template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT, int PF, bool NTL, bool LDSJ, bool JK, bool JHL, int KD, bool PLN>
 struct TileFor {
-  static constexpr bool pln = plane_capable<FP, RANK>() && (PLN || plane_only<FP, RANK>());
-  using type = Tile<pln ? plane_rows<T, FP>(RJ, WJ, WK) : march_rows<FP, RANK>(RJ), WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>;
+  static constexpr bool star = plane_capable<FP, RANK>(), box = planes_capable<T, FP, RANK>();
+  static constexpr bool pln = (star || box) && (PLN || plane_only<T, FP, RANK>());
+  static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : star ? plane_rows<T, FP>(RJ, WJ, WK) : planes_rows<T, FP>(RJ, WJ, WK);
+  using type = Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>;
 };
+// star footprints: the centre plane in LDS, the ring of own cells in registers; box footprints: every live plane in LDS
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
 constexpr auto march_kernel_fn() {
-  if constexpr (TL::PLN) return &neptune_apply_plane<Body, T, NIN, FP, TL>;
+  if constexpr (TL::PLN && FP::BOX) return &neptune_apply_planes<Body, T, NIN, FP, TL>;
+  else if constexpr (TL::PLN) return &neptune_apply_plane<Body, T, NIN, FP, TL>;
   else return &neptune_apply_march<Body, T, RANK, NIN, FP, TL>;
 }
 

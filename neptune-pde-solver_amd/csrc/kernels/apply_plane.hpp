@@ -295,4 +295,241 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   }
 }
 
+// ---- BOX footprints: every live plane in LDS ------------------------------------------------------------------------
+// A box stencil (27-point, 125-point) reads J / K neighbours on EVERY plane of its reach, so the window of every live
+// plane lies in LDS -- NB = 2*R0 + 2 buffers: the 2*R0+1 planes the current step reads and the one being laid out for the
+// next step -- and the registers hold nothing across steps but the loads in flight.  The march kernel serves a box from
+// registers: K neighbours by a wave shift per plane, row and side, with scalar halo cells that have to ride the ring (the
+// 27-point kernel spends 40 % of its vector instructions on moves, shifts and scalar-register spills, two waves per SIMD,
+// profiles/r02_valu_27pt.txt).  Here a tap is an LDS read with a compile-time offset; the plane-to-buffer mapping is
+// compile-time too (the step loop is unrolled NB times).  Traversal, halo-row units and halo cells as in the star kernel
+// above; the halo-row units carry the window's corner cells as well.
+template <class T, class FP>
+constexpr int planes_rows(int rj, int wj, int wk) {
+  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK;
+  while (rj > 1 && (2 * FP::R0 + 2) * (wj * rj + 2 * FP::R1) * (wk * kWave * VK + 2 * HK) * (int)sizeof(T) > 160 * 1024) rj /= 2;
+  return rj;
+}
+template <class T, class FP, int RANK>
+constexpr bool planes_capable() {
+  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK;
+  return RANK == 3 && FP::MARCH_OK && FP::BOX && popcount_u(FP::HALO_MASK) == 1 && FP::R0 >= 1 && FP::R0 <= 2 && FP::R1 <= 2 &&
+         FP::R2 <= 2 && (2 * FP::R0 + 2) * (4 + 2 * FP::R1) * (kWave * VK + 2 * HK) * (int)sizeof(T) <= 160 * 1024;
+}
+
+template <class T, int NIN, class FP, int RJ, int r, int e, int LROW, int PLANE, int PH, int NB>
+struct PlanesAcc {
+  static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2;
+  static constexpr unsigned HMASK = FP::HALO_MASK;
+  using V = typename Vec16<T>::type;
+  const V (&pt)[NIN][RJ];
+  const T* lp;         // LDS: this lane's cell (own row 0, element 0) in buffer 0
+  int64_t li, lj, lk;
+
+  template <int IN, int... O>
+  __device__ __forceinline__ T get() const {
+    static_assert(IN >= 0 && IN < NIN, "input index out of range");
+    constexpr int oi = PickOffset<3, 0, O...>::value, oj = PickOffset<3, 1, O...>::value, ok = PickOffset<3, 2, O...>::value;
+    if constexpr ((HMASK >> IN) & 1u) {
+      static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2, "access outside the declared footprint");
+      return lp[((PH + oi + R0) % NB) * PLANE + (r + oj) * LROW + e + ok];
+    } else {
+      static_assert(oi == 0 && oj == 0 && ok == 0, "only halo inputs may be read at an offset");
+      return pt[IN][r][e];
+    }
+  }
+  template <int D>
+  __device__ __forceinline__ int64_t idx() const {
+    static_assert(D >= 0 && D < 3, "index argument out of range");
+    return D == 0 ? li : (D == 1 ? lj : lk);
+  }
+};
+
+template <class Body, class T, int NIN, class FP, class TL>
+__global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(MarchParams<T, NIN> P, Body body) {
+  constexpr int RJ = TL::RJ, WJ = TL::WJ, WK = TL::WK, PF = TL::PF, NW = WJ * WK;
+  constexpr bool NT = TL::NT;
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, NP = 2 * R0 + 1, NB = NP + 1;
+  constexpr unsigned HMASK = FP::HALO_MASK;
+  static_assert(popcount_u(HMASK) == 1, "planes kernel: one halo input");
+  constexpr int HIN = halo_input_of(HMASK, 0);
+  constexpr int HK = (R2 + VK - 1) / VK * VK;
+  constexpr int TJ = WJ * RJ, SPAN = kWave * VK, TK = WK * SPAN;
+  constexpr int LROW = TK + 2 * HK, LR = TJ + 2 * R1, PLANE = LR * LROW;
+  constexpr int NU = 2 * R1 * WK;
+  constexpr int NHW = NU ? (NU + NW - 1) / NW : 0, NHWX = NHW ? NHW : 1;
+  static_assert(2 * HK <= kWave, "K halo cells are loaded by the first 2*HK lanes");
+  static_assert(NB * PLANE * (int)sizeof(T) <= 160 * 1024, "windows do not fit the LDS");
+  __shared__ __attribute__((aligned(16))) T lds[NB][LR][LROW];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wj = w / WK, wk = w % WK;
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = v % P.nK;
+  const uint32_t t = v / P.nK;
+  const uint32_t jt = t % P.nJ;
+  const uint32_t ct = t / P.nJ;
+  const int32_t j0w = P.rJ0 + (int32_t)(jt * TJ);
+  const int32_t j0 = j0w + wj * RJ;
+  const int32_t kw0 = (int32_t)(kt * (uint32_t)TK);
+  const int32_t kw = kw0 + wk * SPAN;
+  const int32_t k0 = kw + lane * VK;
+  const bool lane_ok = k0 < P.Ks;
+  const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
+  const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
+  const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
+  if (ib >= ie) return;
+  const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
+
+  auto row_bytes = [&](int32_t j) -> uint32_t {
+    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  };
+  auto cell_bytes = [&](int32_t k) -> uint32_t {
+    k = k < 0 ? 0 : (k >= P.N2 ? P.N2 - 1 : k);
+    return (uint32_t)k * (uint32_t)sizeof(T);
+  };
+  uint32_t rowb[RJ];
+  static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[r] = row_bytes(j0 + r); });
+  // halo cells: lanes [0,HK) left of the window, lanes [HK,2HK) right of it (one cell each, clamped)
+  const bool c_left = lane < HK, c_right = lane >= HK && lane < 2 * HK;
+  const uint32_t cell_b = cell_bytes(c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK));
+  const int32_t cell_col = c_left ? lane : HK + TK + (lane - HK);
+  const bool kh_any = R2 > 0 && ((wk == 0 && c_left) || (wk == WK - 1 && c_right));
+  const int32_t kh_dst = (R1 + wj * RJ) * LROW + cell_col;
+  // halo-row units of this wave (row x of the 2*R1 halo rows, wave span s), each with the window's corner cells beside it
+  uint32_t hsrc[NHWX], hcsrc[NHWX];
+  int32_t hdst[NHWX], hcdst[NHWX];
+  bool hc_any[NHWX];
+  static_for<NHW>([&](auto tc) {
+    constexpr int tt = tc;
+    const int u = w + tt * NW;
+    const int x = u / WK, sp = u % WK;
+    const int32_t kc = kw0 + sp * SPAN + lane * VK;
+    const uint32_t rb = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
+    const int32_t lrow = (x < R1 ? x : TJ + x) * LROW;
+    hsrc[tt] = rb + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T);
+    hdst[tt] = u < NU ? lrow + HK + sp * SPAN + lane * VK : -1;
+    hcsrc[tt] = rb + cell_b;
+    hcdst[tt] = lrow + cell_col;
+    hc_any[tt] = R2 > 0 && u < NU && ((sp == 0 && c_left) || (sp == WK - 1 && c_right));
+  });
+
+  // loads in flight: slot d holds the pieces of one plane
+  V nxt[PF][RJ];
+  V jh[PF][NHWX];
+  T kh[PF][RJ], hc[PF][NHWX];
+  V pt[NIN][RJ];
+
+  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
+    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
+  };
+  auto load_plane = [&](int32_t ip, auto dc) {
+    constexpr int d = decltype(dc)::value;
+    const char* base = plane_base(P.in[HIN], ip);
+    static_for<NHW>([&](auto tc) {
+      constexpr int tt = tc;
+      if (hdst[tt] >= 0) jh[d][tt] = *reinterpret_cast<const V*>(base + hsrc[tt]);
+      if (hc_any[tt]) hc[d][tt] = *reinterpret_cast<const T*>(base + hcsrc[tt]);
+    });
+    if constexpr (R2 > 0) {
+      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[d][r] = *reinterpret_cast<const T*>(base + (rowb[r] + cell_b)); });
+    }
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; nxt[d][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+  };
+  const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;
+  auto lay_out = [&](int b, auto dc) {
+    constexpr int d = decltype(dc)::value;
+    T* buf = &lds[0][0][0] + b * PLANE;
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + own_cell + r * LROW) = nxt[d][r]; });
+    static_for<NHW>([&](auto tc) {
+      constexpr int tt = tc;
+      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[d][tt];
+      if (hc_any[tt]) buf[hcdst[tt]] = hc[d][tt];
+    });
+    if constexpr (R2 > 0) {
+      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; buf[kh_dst + r * LROW] = kh[d][r]; });
+    }
+  };
+  auto load_point_row = [&](int32_t ip, auto rc) {
+    constexpr int r = decltype(rc)::value;
+    static_for<NIN>([&](auto nc) {
+      constexpr int n = nc;
+      if constexpr (n != HIN) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
+    });
+  };
+
+  bool in_j[RJ], row_ok[RJ], in_k[VK];
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    in_j[r] = (j0 + r) >= P.plb[1] && (j0 + r) < P.pub[1];
+    row_ok[r] = (j0 + r) < P.rJ1;
+  });
+  static_for<VK>([&](auto ec) {
+    constexpr int e = ec;
+    in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
+  });
+
+  // ---- prologue: planes ib-R0 .. ib+R0 into buffers 0 .. 2*R0 (plane q lives in buffer (q - ib + R0) mod NB), then the
+  // next PF planes in flight
+  static_for<NP>([&](auto pc) {
+    constexpr int p = pc;
+    load_plane(ib - R0 + p, std::integral_constant<int, 0>{});
+    lay_out(p, std::integral_constant<int, 0>{});
+  });
+  static_for<PF>([&](auto dc) { constexpr int d = dc; load_plane(ib + R0 + 1 + d, dc); });
+  static_for<RJ>([&](auto rc) { load_point_row(ib, rc); });
+
+  // one plane step at phase ph = (i - ib) mod NB: barrier (every buffer the step reads is complete, the buffer of plane
+  // i-R0-1 free) -> lay plane i+R0+1 out there -> request plane i+R0+1+PF -> compute plane i
+  auto step = [&](const int32_t i, auto phase_c) {
+    constexpr int ph = decltype(phase_c)::value % NB;
+    constexpr int slot = decltype(phase_c)::value % PF;
+    __syncthreads();
+    lay_out((ph + NB - 1) % NB, std::integral_constant<int, slot>{});
+    load_plane(i + R0 + 1 + PF, std::integral_constant<int, slot>{});
+
+    const bool in_i = i >= P.plb[0] && i < P.pub[0];
+    const int64_t li = (int64_t)i + P.olb[0];
+    char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
+    const T* lp = &lds[0][0][0] + own_cell;
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      const int64_t lj = (int64_t)(j0 + r) + P.olb[1];
+      const bool in_ij = in_i && in_j[r];
+      V res;
+      static_for<VK>([&](auto ec) {
+        constexpr int e = ec;
+        const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
+        const bool inside = in_ij && in_k[e];
+        PlanesAcc<T, NIN, FP, RJ, r, e, LROW, PLANE, ph, NB> acc{pt, lp, li, lj, lk};
+        const T val = body(acc);
+        T through;
+        if constexpr (HMASK & 1u) through = lp[((ph + R0) % NB) * PLANE + r * LROW + e];
+        else through = pt[0][r][e];
+        res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
+      });
+      if (row_ok[r] && lane_ok) {
+        V* dst = reinterpret_cast<V*>(obase + (rowb[r] + lane_b));
+        if constexpr (NT) __builtin_nontemporal_store(res, dst);
+        else *dst = res;
+      }
+      if constexpr (NIN > 1) load_point_row(i + 1, rc);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  constexpr int UNROLL = (NB % PF == 0) ? NB : NB * PF;   // phases and slots both stay compile-time
+  for (int32_t i = ib; i < ie; i += UNROLL) {
+    static_for<UNROLL>([&](auto phc) {
+      constexpr int ph = phc;
+      if (i + ph < ie) step(i + ph, phc);
+    });
+  }
+}
+
 }  // namespace neptune_hip

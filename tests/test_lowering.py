@@ -285,7 +285,9 @@ def test_footprint_limits_of_the_march_kernel():
     assert kernel_of((1024,), "f64", [(0, o) for o in mh.star(1, 5)], 5)[0] == "direct"
     # boxes: 27 points in 3-D, 5x5 in 2-D
     box3 = [(0, (a, b, c)) for a in (-2, 0, 2) for b in (-1, 1) for c in (-2, 2)]
-    assert kernel_of((16, 16, 128), "f64", box3, 2)[0] == "direct"
+    assert kernel_of((16, 16, 128), "f64", box3, 2)[0] == "march"       # radius-2 boxes: every live plane in LDS
+    box3 = [(0, (a, b, c)) for a in (-3, 0, 3) for b in (-1, 1) for c in (-2, 2)]
+    assert kernel_of((16, 16, 128), "f64", box3, 3)[0] == "direct"
     box2 = [(0, (a, b)) for a in range(-3, 4) for b in (-3, 3)]
     assert kernel_of((32, 256), "f64", box2, 3)[0] == "direct"
 

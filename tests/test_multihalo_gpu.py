@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 # exactly representable, all different, so a swapped operand or ring slot changes bits
 COEF = [0.5, -0.25, 1.5, 0.125, -0.75, 2.0, -1.25, 0.375, 0.0625, -3.0, 1.75, 0.3125, -0.4375, 2.5, -0.1875, 0.875,
         1.125, -2.25, 0.6875, -0.5625, 3.5, -1.375, 0.21875, 0.9375, -1.625, 2.75, -0.3125, 1.0625]
-COEF = COEF + [c * 0.5 + 0.03125 for c in COEF]   # 49 taps for a radius-8 star: dyadic, so every product stays exact-ish and distinct
+COEF = COEF + [c * 0.5 + 0.03125 for c in COEF]   # 49 taps for a radius-8 star: dyadic and distinct
+COEF = COEF + [c * 0.25 - 0.015625 for c in COEF] + [0.75 - c * 0.125 for c in COEF]   # 168: a 5x5x5 box has 125 taps
 
 
 def module_text(shape, elem, nin, accesses, lb, ub):
@@ -134,6 +135,10 @@ CASES = {
     "unequal_radii_3d": ((11, 30, 256), "f64", 1,
                          [(0, (0, 0, 0)), (0, (-2, 0, 0)), (0, (1, 0, 0)), (0, (0, -5, 0)), (0, (0, 3, 0)), (0, (0, 0, 1)), (0, (0, 0, -3))],
                          5, "march"),
+    # 3-D boxes of radius 2 (every live plane in LDS: neptune_apply_planes); the march kernel's registers stop at 27 points
+    "box125_3d_f32": ((9, 20, 256), "f32", 1, [(0, (a, b, c)) for a in range(-2, 3) for b in range(-2, 3) for c in range(-2, 3)], 2, "march"),
+    "box_radius2_sparse_3d": ((8, 13, 130), "f64", 1,
+                              [(0, (a, b, c)) for a in (-2, 0, 1) for b in (-2, -1, 2) for c in (-1, 0, 2)] + [(0, (0, 0, 0))], 2, "march"),
     "radius3_jk_only_3d": ((7, 21, 384), "f32", 1, [(0, o) for o in star(3, 3) if o[0] == 0], 3, "march"),
 }
 
