@@ -158,8 +158,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   // PHASED: the ring is never moved -- the step loop is unrolled NS times and step phase ph finds plane offset oi in slot
   // (ph + oi + RR) mod NS; the load of plane i+RR+PF goes straight into the slot of the plane that has just left the
   // stencil's reach.  (Rotating the ring costs (NP-1)*RJ 16-byte moves per step: 17 % of the vector instructions of a
-  // radius-4 step.)  Long rings keep the rotation: NS copies of the step would not fit the instruction cache.  Slots
-  // NP.. are the planes in flight then.
+  // radius-4 step.)  NS copies of the step must fit the instruction cache (64 KiB per two CUs; radius 4: 46 KiB; radius 5 with
+  // three rows per lane was tried: 62 KiB, no faster than two rows and a rotated ring; radius 8 would be 110 KiB): rings beyond
+  // 10 slots keep the rotation, slots NP.. being the planes in flight then.
   constexpr int RR = R0 > 1 ? R0 : 1, NPR = 2 * RR + 1;
   constexpr int NS = NPR + PF;
   constexpr bool PHASED = NS <= 10;
