@@ -242,7 +242,10 @@ constexpr int march_rows(int rj) {
 // hold (radius beyond 4) run it on EVERY row
 template <class T, class FP, int RANK>
 constexpr bool plane_only() {
-  return (plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4)) ||
+  constexpr int NH = popcount_u(FP::HALO_MASK);
+  constexpr bool wide = FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1;
+  // what the march kernel's registers cannot hold: stars beyond radius 4, two inputs read at offsets beyond radius 1, three or more
+  return (plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4 || (NH > 1 && wide) || NH > 2)) ||
          (planes_capable<T, FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1));
 }
 template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT, int PF, bool NTL, bool LDSJ, bool JK, bool JHL, int KD, bool PLN>
@@ -424,7 +427,8 @@ inline int pick_march_variant(const neptune_hip_apply_geom_t* g, const neptune_h
     // 3-D stars of radius 2 and more (13-, 19-, 25-point operators ...): the plane-in-LDS kernel, four own rows per lane
     // (512^3 fp64: radius 2 4.96 TB/s against 4.53 on tile 2, radius 3 4.6 against 3.6, radius 4 4.1 against 2.8 on tile 5;
     // profiles/r02_plane.txt)
-    constexpr bool kPlane = plane_capable<FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1);
+    // ... and from two inputs read at offsets on at any radius (two 7-point stars 512^3: 5.46 TB/s against 5.18 on tile 2)
+    constexpr bool kPlane = plane_capable<FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1 || kNH > 1);
     variant = RANK == 3 ? (kPlane ? 7 : kWideState ? (FP::R0 > 3 ? 5 : 2) : FP::BOX ? 1 : 0)
                         : (RANK == 2 && (kNH > 2 || FP::R0 > 2 || (FP::BOX && FP::R0 > 1))) ? 1 : (RANK == 2 && kNH == 2) ? 2 : 0;
     if constexpr (RANK == 3) {

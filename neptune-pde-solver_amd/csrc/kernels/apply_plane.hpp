@@ -30,34 +30,41 @@
 
 namespace neptune_hip {
 
-// can the plane kernel run this footprint?  rank 3, one halo input, star, radii that leave a window in LDS
+// can the plane kernel run this footprint?  rank 3, star, radii that leave a window in LDS; several inputs read at offsets
+// (systems of equations: h and q of a shallow-water residual at 4th order) each get a ring and a window of their own, as
+// long as two rows per lane of all rings stay below ~170 VGPRs: NH * (2*max(R0,1)+2) <= 21 -- two inputs up to radius 4,
+// three up to radius 2, four at radius 1
+template <class FP>
+constexpr int plane_slots() { return 2 * (FP::R0 > 1 ? FP::R0 : 1) + 2; }   // ring slots per halo input at PF = 1
 template <class FP, int RANK>
 constexpr bool plane_capable() {
-  return RANK == 3 && FP::MARCH_OK && !FP::BOX && popcount_u(FP::HALO_MASK) == 1 && (FP::R1 > 0 || FP::R2 > 0) && FP::R0 <= 8 &&
-         FP::R1 <= 8 && FP::R2 <= 8;
+  constexpr int NH = popcount_u(FP::HALO_MASK);
+  return RANK == 3 && FP::MARCH_OK && !FP::BOX && NH >= 1 && NH * plane_slots<FP>() <= (NH == 1 ? 18 : 21) &&
+         (FP::R1 > 0 || FP::R2 > 0) && FP::R0 <= 8 && FP::R1 <= 8 && FP::R2 <= 8;
 }
-// rows per lane the plane kernel gives a footprint on a WJ x WK window: the ring is (2*R0+1) * RJ * 4 VGPRs (kept below
-// ~150 of the 256 a wave has at two waves per SIMD), and the double-buffered window must fit the CU's 160 KiB of LDS
+// rows per lane the plane kernel gives a footprint on a WJ x WK window: the rings are NH * slots * RJ * 4 VGPRs (kept below
+// ~170 of the 256 a wave has at two waves per SIMD), and the double-buffered windows must fit the CU's 160 KiB of LDS
 template <class T, class FP>
 constexpr int plane_rows(int rj, int wj, int wk) {
-  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK;
-  while (rj > 1 && (2 * FP::R0 + 1) * rj * 4 > 150) rj /= 2;
-  while (rj > 1 && 2 * (wj * rj + 2 * FP::R1) * (wk * kWave * VK + 2 * HK) * (int)sizeof(T) > 160 * 1024) rj /= 2;
+  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK, NH = popcount_u(FP::HALO_MASK);
+  while (rj > 1 && NH * plane_slots<FP>() * rj * 4 > 168) rj /= 2;
+  while (rj > 1 && 2 * NH * (wj * rj + 2 * FP::R1) * (wk * kWave * VK + 2 * HK) * (int)sizeof(T) > 160 * 1024) rj /= 2;
   return rj;
 }
 
 // PH / NS / RR: the ring is addressed in place -- plane offset oi of the current step lives in slot (PH + oi + RR) mod NS
 // (RR: planes the ring keeps on each side of the centre, max(R0, 1))
-template <class T, int NIN, class FP, int RJ, int r, int e, int LROW, int PH, int NS, int RR>
+template <class T, int NIN, class FP, int RJ, int r, int e, int LROW, int WIN, int PH, int NS, int RR>
 struct PlaneAcc {
   static constexpr int VK = 16 / sizeof(T);
   static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, NP = 2 * R0 + 1;
   static constexpr unsigned HMASK = FP::HALO_MASK;
   using V = typename Vec16<T>::type;
 
-  const V (&ring)[NS][RJ];
+  static constexpr int NH = popcount_u(HMASK);
+  const V (&ring)[NH][NS][RJ];
   const V (&pt)[NIN][RJ];
-  const T* lp;         // LDS: this lane's cell (own row 0, element 0) of the centre plane
+  const T* lp;         // LDS: this lane's cell (own row 0, element 0) of the centre plane of halo input 0; input h: + h * WIN
   int64_t li, lj, lk;  // logical coordinates
 
   template <int IN, int... O>
@@ -68,8 +75,9 @@ struct PlaneAcc {
       static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2, "access outside the declared footprint");
       static_assert((oi != 0) + (oj != 0) + (ok != 0) <= 1, "star footprint declared but a diagonal access is used");
       // I neighbours and the J neighbours that are own rows of this lane sit in the ring; the rest is read from LDS
-      if constexpr (ok == 0 && r + oj >= 0 && r + oj < RJ) return ring[(PH + oi + RR) % NS][r + oj][e];
-      else return lp[(r + oj) * LROW + e + ok];
+      constexpr int h = halo_slot(HMASK, IN);
+      if constexpr (ok == 0 && r + oj >= 0 && r + oj < RJ) return ring[h][(PH + oi + RR) % NS][r + oj][e];
+      else return lp[h * WIN + (r + oj) * LROW + e + ok];
     } else {
       static_assert(oi == 0 && oj == 0 && ok == 0, "only halo inputs may be read at an offset");
       return pt[IN][r][e];
@@ -89,18 +97,19 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   constexpr bool NT = TL::NT;
   using V = typename Vec16<T>::type;
   constexpr int VK = 16 / sizeof(T);
-  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2, NP = 2 * R0 + 1;
+  constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2;
   constexpr unsigned HMASK = FP::HALO_MASK;
-  static_assert(popcount_u(HMASK) == 1 && !FP::BOX, "plane kernel: one halo input, star footprint");
-  constexpr int HIN = halo_input_of(HMASK, 0);
+  constexpr int NH = popcount_u(HMASK);       // inputs read at offsets: a ring and a window each
+  static_assert(NH >= 1 && !FP::BOX, "plane kernel: star footprint");
   constexpr int HK = (R2 + VK - 1) / VK * VK;  // halo cells kept per side (whole lane vectors keep own cells 16-byte aligned)
   constexpr int TJ = WJ * RJ, SPAN = kWave * VK, TK = WK * SPAN;
-  constexpr int LROW = TK + 2 * HK, LR = TJ + 2 * R1;
-  constexpr int NU = 2 * R1 * WK;              // halo-row units (one row x one wave span), dealt over the waves
-  constexpr int NHW = NU ? (NU + NW - 1) / NW : 0, NHWX = NHW ? NHW : 1;
+  constexpr int LROW = TK + 2 * HK, LR = TJ + 2 * R1, WIN = LR * LROW;
+  constexpr int NU = 2 * R1 * WK;              // halo-row units per input (one row x one wave span), all dealt over the waves
+  constexpr int NUA = NH * NU;
+  constexpr int NHW = NUA ? (NUA + NW - 1) / NW : 0, NHWX = NHW ? NHW : 1;
   static_assert(2 * HK <= kWave, "K halo cells are loaded by the first 2*HK lanes");
-  static_assert(2 * LR * LROW * (int)sizeof(T) <= 160 * 1024, "window does not fit the LDS");
-  __shared__ __attribute__((aligned(16))) T lds[2][LR][LROW];
+  static_assert(2 * NH * WIN * (int)sizeof(T) <= 160 * 1024, "windows do not fit the LDS");
+  __shared__ __attribute__((aligned(16))) T lds[2][NH][LR][LROW];
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -132,16 +141,22 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   uint32_t rowb[RJ];
   static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[r] = row_bytes(j0 + r); });
 
-  // halo-row units of this wave: unit u = w + t*NW -> halo row x = u / WK (x < R1: above the window), wave span u % WK
-  uint32_t hsrc[NHWX];   // byte offset within a plane of my 16 bytes of the unit
-  int32_t hdst[NHWX];    // LDS cell index (within one buffer) they go to; -1: no unit
+  // halo-row units of this wave: unit uu = w + t*NW -> halo input uu / NU, halo row x = (uu % NU) / WK (x < R1: above the
+  // window), wave span (uu % NU) % WK.  All inputs share the result's box, so a unit's offset within a plane does not
+  // depend on its input; only the base pointer does.
+  uint32_t hsrc[NHWX];      // byte offset within a plane of my 16 bytes of the unit
+  int32_t hdst[NHWX];       // LDS cell index (within one buffer) they go to; -1: no unit
+  const T* hfield[NHWX];    // the unit's input
   static_for<NHW>([&](auto tc) {
     constexpr int tt = tc;
-    const int u = w + tt * NW;
-    const int x = u / WK, s = u % WK;
-    const int32_t kc = kw0 + s * SPAN + lane * VK;
+    const int uu = w + tt * NW;
+    const int hh = NU ? uu / NU : 0, u = NU ? uu % NU : 0;
+    const int x = u / WK, sp = u % WK;
+    const int32_t kc = kw0 + sp * SPAN + lane * VK;
     hsrc[tt] = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1)) + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T);
-    hdst[tt] = u < NU ? (x < R1 ? x : TJ + x) * LROW + HK + s * SPAN + lane * VK : -1;
+    hdst[tt] = uu < NUA ? hh * WIN + (x < R1 ? x : TJ + x) * LROW + HK + sp * SPAN + lane * VK : -1;
+    hfield[tt] = P.in[halo_input_of(HMASK, 0)];
+    static_for<NH>([&](auto hc) { constexpr int h = hc; if (hh == h) hfield[tt] = P.in[halo_input_of(HMASK, h)]; });
   });
   // halo cells beside my own rows: lanes [0,HK) the cells left of the window (its leftmost waves), lanes [HK,2HK) the
   // cells right of it (its rightmost waves); clamped per cell
@@ -152,47 +167,54 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   const uint32_t kh_b = (uint32_t)khc * (uint32_t)sizeof(T);
   const int32_t kh_dst = (R1 + wj * RJ) * LROW + (kh_left ? lane : HK + TK + (lane - HK));
 
-  // ---- register state: the ring of own cells with the planes in flight, the halo pieces in flight ----
-  // The ring keeps RR = max(R0, 1) planes on each side of the centre (the plane AFTER the centre is laid out in LDS one
+  // ---- register state: per halo input the ring of own cells with the planes in flight; the halo pieces in flight ----
+  // A ring keeps RR = max(R0, 1) planes on each side of the centre (the plane AFTER the centre is laid out in LDS one
   // step ahead, so it must have arrived even when the body reads no I neighbour) plus the PF planes in flight: NS slots.
   // PHASED: the ring is never moved -- the step loop is unrolled NS times and step phase ph finds plane offset oi in slot
   // (ph + oi + RR) mod NS; the load of plane i+RR+PF goes straight into the slot of the plane that has just left the
   // stencil's reach.  (Rotating the ring costs (NP-1)*RJ 16-byte moves per step: 17 % of the vector instructions of a
   // radius-4 step.)  NS copies of the step must fit the instruction cache (64 KiB per two CUs; radius 4: 46 KiB; radius 5 with
   // three rows per lane was tried: 62 KiB, no faster than two rows and a rotated ring; radius 8 would be 110 KiB): rings beyond
-  // 10 slots keep the rotation, slots NP.. being the planes in flight then.
+  // 10 slots keep the rotation, slots NPR.. being the planes in flight then.
   constexpr int RR = R0 > 1 ? R0 : 1, NPR = 2 * RR + 1;
   constexpr int NS = NPR + PF;
   constexpr bool PHASED = NS <= 10;
   constexpr int UNROLL = PHASED ? NS : PF;
-  V ring[NS][RJ];
-  V jh[NHWX];   // my halo-row units and halo cells of the plane after next's centre... of plane i+2 while step i computes
-  T kh[RJ];
+  V ring[NH][NS][RJ];
+  V jh[NHWX];   // my halo-row units and halo cells of plane i+2 while step i computes
+  T kh[NH][RJ];
   V pt[NIN][RJ];   // inputs read at the centre only: row r of the next plane is requested as soon as row r has been computed
 
   auto plane_base = [&](const T* field, int32_t ip) -> const char* {
     const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
     return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
   };
-  auto load_rows = [&](int32_t ip, V(&rows)[RJ]) {
-    const char* base = plane_base(P.in[HIN], ip);
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; rows[r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+  auto load_rows = [&](int32_t ip, auto slot_c) {
+    constexpr int sl = decltype(slot_c)::value;
+    static_for<NH>([&](auto hc) {
+      constexpr int h = hc;
+      const char* base = plane_base(P.in[halo_input_of(HMASK, h)], ip);
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[h][sl][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+    });
   };
-  auto load_halos = [&](int32_t ip, V(&hrows)[NHWX], T(&hcells)[RJ]) {
-    const char* base = plane_base(P.in[HIN], ip);
+  auto load_halos = [&](int32_t ip) {
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
-      if (hdst[tt] >= 0) hrows[tt] = *reinterpret_cast<const V*>(base + hsrc[tt]);
+      if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(plane_base(hfield[tt], ip) + hsrc[tt]);
     });
     if constexpr (R2 > 0) {
-      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; hcells[r] = *reinterpret_cast<const T*>(base + (rowb[r] + kh_b)); });
+      if (kh_any) static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        const char* base = plane_base(P.in[halo_input_of(HMASK, h)], ip);
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[h][r] = *reinterpret_cast<const T*>(base + (rowb[r] + kh_b)); });
+      });
     }
   };
   auto load_point_row = [&](int32_t ip, auto rc) {
     constexpr int r = decltype(rc)::value;
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
-      if constexpr (n != HIN) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
+      if constexpr (!((HMASK >> n) & 1u)) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
     });
   };
 
@@ -207,31 +229,39 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
   });
 
-  const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;  // my cell (own row 0, element 0) in a buffer
-  // lay a plane out in LDS buffer `b`: my own rows (from the ring), my halo-row units, the halo cells beside my rows
-  auto lay_out = [&](int b, const V(&rows)[RJ]) {
-    T* buf = &lds[b][0][0];
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + own_cell + r * LROW) = rows[r]; });
+  const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;  // my cell (own row 0, element 0) in a window
+  // lay a plane out in LDS buffer `b`: per halo input my own rows (from its ring slot), then my halo-row units and the halo
+  // cells beside my rows
+  auto lay_out = [&](int b, auto slot_c) {
+    constexpr int sl = decltype(slot_c)::value;
+    T* buf = &lds[b][0][0][0];
+    static_for<NH>([&](auto hc) {
+      constexpr int h = hc;
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) = ring[h][sl][r]; });
+    });
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
       if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[tt];
     });
     if constexpr (R2 > 0) {
-      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; buf[kh_dst + r * LROW] = kh[r]; });
+      if (kh_any) static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; buf[h * WIN + kh_dst + r * LROW] = kh[h][r]; });
+      });
     }
   };
 
   // ---- prologue: planes ib-RR .. ib+RR+PF-1 (the last PF of them stay in flight); plane ib laid out in buffer 0, the
   // halos of plane ib+1 in flight
-  load_halos(ib, jh, kh);
+  load_halos(ib);
   static_for<NS - 1>([&](auto pc) {
     constexpr int p = pc;
     // phased: plane ib-RR+p -> slot p.  rotating: slots 1.. (shifted down at the top of the first step)
-    load_rows(ib - RR + p, ring[PHASED ? p : p + 1]);
+    load_rows(ib - RR + p, std::integral_constant<int, PHASED ? p : p + 1>{});
   });
   static_for<RJ>([&](auto rc) { load_point_row(ib, rc); });
-  lay_out(0, ring[PHASED ? RR : RR + 1]);
-  load_halos(ib + 1, jh, kh);
+  lay_out(0, std::integral_constant<int, PHASED ? RR : RR + 1>{});
+  load_halos(ib + 1);
 
   // One plane step.  Order: barrier (buffer i&1 is complete, the other one free) -> lay plane i+1 out in the other buffer
   // (its halos were requested a step ago) -> request the halos of plane i+2 and the rows of plane i+RR+PF -> compute
@@ -241,25 +271,28 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     constexpr int slot = decltype(phase_c)::value % PF;
     constexpr int CS = (ph + RR) % NS;                            // slot of the centre plane
     if constexpr (!PHASED) {
-      static_for<NPR - 1>([&](auto pc) {
-        constexpr int p = pc;
-        static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[p][r] = ring[p + 1][r]; });
+      static_for<NH>([&](auto hc) {
+        constexpr int h = hc;
+        static_for<NPR - 1>([&](auto pc) {
+          constexpr int p = pc;
+          static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[h][p][r] = ring[h][p + 1][r]; });
+        });
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[h][NPR - 1][r] = ring[h][NPR + slot][r]; });
       });
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[NPR - 1][r] = ring[NPR + slot][r]; });
     }
 
     __syncthreads();
     // no "is that plane still in my chunk?" tests here: plane indices are clamped into the field, so the few loads past
     // the chunk's end are harmless, and straight-line code lets the compiler count its waits exactly (with the tests it
     // drained vmcnt to zero at the top of every step)
-    lay_out((i + 1 - ib) & 1, ring[(CS + 1) % NS]);
-    load_halos(i + 2, jh, kh);
-    load_rows(i + PF + RR, ring[PHASED ? (ph + NS - 1) % NS : NPR + slot]);
+    lay_out((i + 1 - ib) & 1, std::integral_constant<int, (CS + 1) % NS>{});
+    load_halos(i + 2);
+    load_rows(i + PF + RR, std::integral_constant<int, PHASED ? (ph + NS - 1) % NS : NPR + slot>{});
 
     const bool in_i = i >= P.plb[0] && i < P.pub[0];
     const int64_t li = (int64_t)i + P.olb[0];
     char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
-    const T* lp = &lds[(i - ib) & 1][0][0] + own_cell;
+    const T* lp = &lds[(i - ib) & 1][0][0][0] + own_cell;
     static_for<RJ>([&](auto rc) {
       constexpr int r = rc;
       const int64_t lj = (int64_t)(j0 + r) + P.olb[1];
@@ -269,10 +302,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
         constexpr int e = ec;
         const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
         const bool inside = in_ij && in_k[e];
-        PlaneAcc<T, NIN, FP, RJ, r, e, LROW, ph, NS, RR> acc{ring, pt, lp, li, lj, lk};
+        PlaneAcc<T, NIN, FP, RJ, r, e, LROW, WIN, ph, NS, RR> acc{ring, pt, lp, li, lj, lk};
         const T val = body(acc);
         T through;
-        if constexpr (HMASK & 1u) through = ring[CS][r][e];
+        if constexpr (HMASK & 1u) through = ring[0][CS][r][e];   // input 0 owns ring 0
         else through = pt[0][r][e];
         res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
@@ -281,7 +314,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }
-      if constexpr (NIN > 1) load_point_row(i + 1, rc);
+      if constexpr (NIN > NH) load_point_row(i + 1, rc);
       // one row at a time: without the fence the scheduler hoists every row's LDS reads to the top of the step and the
       // 2*(R1+R2) neighbour vectors of ALL rows are live at once (radius 4: 120 VGPRs, spills)
       __builtin_amdgcn_sched_barrier(0);

@@ -304,6 +304,11 @@ struct Emitter {
     // 3-D stars of one halo input beyond that, up to radius 8 (10th- to 16th-order operators): the plane-in-LDS kernel
     // (apply_plane.hpp) keeps only the ring of own cells in registers and reads J / K neighbours from the centre plane in LDS
     if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs == 1 && rbig <= 8) fp.march_ok = true;
+    // ... and several inputs read at offsets, a ring and an LDS window each, while two rows per lane of all rings fit the
+    // registers: inputs * (2*max(R0,1)+2) <= 21 (apply_plane.hpp plane_capable)
+    if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs >= 2 && rbig <= 8 && (R[1] > 0 || R[2] > 0) &&
+        fp.halo_inputs * (2 * std::max(R[0], 1) + 2) <= 21)
+      fp.march_ok = true;
     // 3-D boxes of one halo input up to radius 2 (125 points): every live plane in LDS (neptune_apply_planes)
     if (!fp.march_ok && rank == 3 && fp.box && fp.halo_inputs == 1 && rbig <= 2 && R[0] >= 1) fp.march_ok = true;
     if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }

@@ -245,6 +245,10 @@ def test_several_halo_inputs_get_a_mask_and_shared_radii():
     assert rep["applies"][0]["kernel"] == "march"
     shape, elem, nin, accesses, _, _ = mh.CASES["radius2_pair_3d"]
     src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [2, 2, 2], [n - 2 for n in shape]))
+    assert "neptune_hip::Footprint<0, 2, 2, 2, false, true, 0x3u>" in src      # two rings + two LDS windows (plane kernel)
+    assert rep["applies"][0]["kernel"] == "march"
+    shape, elem, nin, accesses, _, _ = mh.CASES["radius5_pair_3d"]
+    src, rep = lowering.to_hip(mh.module_text(shape, elem, nin, accesses, [5, 5, 5], [n - 5 for n in shape]))
     assert "neptune_hip::Footprint<-1, 0, 0, 0, false, false>" in src
     assert rep["applies"][0]["kernel"] == "direct"
     shape, elem, nin, accesses, _, _ = mh.CASES["four_halo_inputs_2d"]
@@ -277,7 +281,7 @@ def test_footprint_limits_of_the_march_kernel():
     assert kernel_of((40, 40, 128), "f64", [(0, o) for o in mh.star(3, 9) if max(map(abs, o)) in (0, 9)], 9)[0] == "direct"
     two = [(0, o) for o in mh.star(3, 5)] + [(1, o) for o in mh.star(3, 1)[1:]]
     src, rep = lowering.to_hip(mh.module_text((24, 24, 128), "f64", 2, two, [5] * 3, [19] * 3))
-    assert rep["applies"][0]["kernel"] == "direct"                  # two halo inputs beyond radius 1: direct
+    assert rep["applies"][0]["kernel"] == "direct"                  # two halo inputs: up to radius 4
     # 1-D: the K radius may reach two lane vectors (8 f32 cells, 4 f64 cells)
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 8)], 8)[0] == "march"
     assert kernel_of((1024,), "f32", [(0, o) for o in mh.star(1, 9)], 9)[0] == "direct"

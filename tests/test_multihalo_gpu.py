@@ -121,7 +121,13 @@ CASES = {
     "radius3_3d_f32_ragged": ((13, 17, 261), "f32", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius4_3d": ((12, 14, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "march"),
     "radius4_3d_f32": ((13, 12, 260), "f32", 1, [(0, o) for o in star(3, 4)], 4, "march"),
-    "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "direct"),
+    "radius2_pair_3d": ((9, 10, 128), "f64", 2, [(0, o) for o in star(3, 2)] + [(1, o) for o in star(3, 2)[1:]], 2, "march"),
+    # several inputs read at offsets beyond what the march kernel's registers hold: a ring and an LDS window each in the plane kernel
+    "radius4_pair_3d": ((12, 37, 256), "f64", 2, [(0, o) for o in star(3, 4)[:13]] + [(1, o) for o in star(3, 4)[1:] if o[0] == 0 or abs(o[0]) == 4], 4, "march"),
+    "radius2_triple_3d_f32": ((9, 20, 515), "f32", 3, [(k, o) for k in range(3) for o in star(3, 2)[k:7 + 2 * k]], 2, "march"),
+    "four_stars_3d": ((7, 36, 128), "f64", 4, [(k, o) for k in range(4) for o in star(3, 1)[k % 2:]], 1, "march"),
+    "point0_two_wide_stars_3d": ((11, 12, 130), "f64", 3, [(0, (0, 0, 0))] + [(1, o) for o in star(3, 3)] + [(2, o) for o in star(3, 2)[1:]], 3, "march"),
+    "radius5_pair_3d": ((14, 15, 128), "f64", 2, [(0, o) for o in star(3, 5)] + [(1, o) for o in star(3, 1)], 5, "direct"),
     # the plane-in-LDS kernel (apply_plane.hpp): 3-D stars of one halo input, radius 3-4 by default and up to radius 8 on
     # every tile (beyond radius 4 nothing else holds the ring); a second input read at the centre (leapfrog schemes);
     # unequal radii per axis; a window two waves wide is reached through the full variant list only
