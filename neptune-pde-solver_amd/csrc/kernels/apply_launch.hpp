@@ -252,8 +252,13 @@ template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT
 struct TileFor {
   static constexpr bool star = plane_capable<FP, RANK>(), box = planes_capable<T, FP, RANK>();
   static constexpr bool pln = (star || box) && (PLN || plane_only<T, FP, RANK>());
-  static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : star ? plane_rows<T, FP>(RJ, WJ, WK) : planes_rows<T, FP>(RJ, WJ, WK);
-  using type = Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>;
+  // a march row that only lands here because nothing else can hold the footprint becomes one of TWO plane tiles (the 8-wave
+  // default, or the 4-wave one for the small-field rows): eight different plane kernels per apply would only cost compile time
+  static constexpr bool canon = pln && !PLN;
+  static constexpr int wj = canon ? (WJ * WK <= 4 ? 4 : 8) : WJ, wk = canon ? 1 : WK, rj = canon ? 4 : RJ;
+  static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : star ? plane_rows<T, FP>(rj, wj, wk) : planes_rows<T, FP>(rj, wj, wk);
+  using type = std::conditional_t<canon, Tile<rows, wj, 1, true, true, 1, false, true, false, true, 1, true>,
+                                  Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>>;
 };
 // star footprints: the centre plane in LDS, the ring of own cells in registers; box footprints: every live plane in LDS
 template <class Body, class T, int RANK, int NIN, class FP, class TL>

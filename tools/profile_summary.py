@@ -27,6 +27,12 @@ def short(name):
                   (f"_kd{kd}" if kd != "1" else "") + ("_ntl" if f(6) else "")
         tag += ("" if f(3) else "_shfl") + ("" if f(4) else "_plainst")
         return "neptune_apply_march[" + tag + "]"
+    m = re.search(r"neptune_apply_planes?<.*?Tile<([^>]*)>", name)
+    if m:   # plane-in-LDS kernels (apply_plane.hpp): only RJ, WJ, WK, PF of the tile mean anything there
+        a = [x.strip() for x in m.group(1).split(",")]
+        return ("neptune_apply_planes[" if "apply_planes<" in name else "neptune_apply_plane[") + f"pln_rj{a[0]}_wj{a[1]}_wk{a[2]}_pf{a[5]}]"
+    if "neptune_apply_plane" in name:
+        return "neptune_apply_plane" + ("s" if "apply_planes<" in name else "")
     m = re.search(r"neptune_apply_march2<.*?, (\d+), (\d+), \d+>", name)
     if m:
         return f"neptune_apply_march2[rows{m.group(1)}x{m.group(2)}]"
