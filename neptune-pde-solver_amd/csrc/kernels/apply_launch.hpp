@@ -10,6 +10,8 @@
 //   * march kernel when: footprint allows it, rank >= 2, all inputs share the result's box,
 //     the contiguous extent is a multiple of the 16-byte lane vector and at least one wave
 //     wide, all base pointers are 16-byte aligned, and the region only restricts dim 0.
+//     A march tile index may stand for the plane-in-LDS kernels (apply_plane.hpp): tile 7 for every footprint they can run,
+//     every index for footprints nothing else holds (3-D stars beyond radius 4, several wide halo inputs, radius-2 boxes).
 //   * otherwise the direct kernel.
 #pragma once
 #include <array>

@@ -1,5 +1,8 @@
-// apply_plane.hpp -- rank-3 STAR stencils of any radius: the march kernel's traversal with the centre plane's
-// neighbourhood in LDS instead of registers.
+// apply_plane.hpp -- rank-3 stencils whose neighbourhood does not fit the march kernel's registers: the march kernel's
+// traversal with the J / K neighbourhood in LDS.  Two kernels:
+//   neptune_apply_plane   STAR footprints (radius up to 8, one or several inputs read at offsets): the ring of the lane's own
+//                         cells in registers, the centre plane's window in LDS
+//   neptune_apply_planes  BOX footprints of radius 2: the windows of all live planes in LDS (second half of this file)
 //
 // A star reads its I neighbours (dim 0) on the cell's own (row, column) and its J / K neighbours on the centre plane only.
 // The march kernel (apply_march.hpp) serves the J / K neighbours from registers: halo rows exchanged through LDS INTO
@@ -8,16 +11,18 @@
 // copies and 2*R2 scalar halo cells per row leave room for TWO own rows per lane next to the 2*R0+1 ring planes -- 16 KiB
 // of row loads in flight per CU, and the kernel is latency-bound at a third of the HBM rate (profiles/r01_highorder.txt).
 //
-// Here the registers hold nothing but the ring of the lane's OWN cells (2*R0+1 planes x RJ rows x 16 B) and the planes in
-// flight.  Every step the workgroup lays the plane that has just become the centre out in LDS -- its own rows, the R1
-// rows above and below its window and the R2 cells left and right of it -- and the body reads J and K neighbours straight
-// from there (ds_read with compile-time offsets; nothing staged in registers, no wave shifts, no scalar halo cells).
-// That frees the registers for FOUR own rows per lane at radius 4 and makes every radius up to 8 fit (RJ = 2).
+// Here the registers hold nothing but, per input read at offsets, the ring of the lane's OWN cells (2*R0+1 planes x RJ rows
+// x 16 B, never moved: addressed by a compile-time phase) and the planes in flight.  Every step the workgroup lays the plane
+// that becomes the centre NEXT step out in LDS -- its own rows, the R1 rows above and below its window and the R2 cells left
+// and right of it -- and the body reads J and K neighbours straight from there (ds_read with compile-time offsets; nothing
+// staged in registers, no wave shifts, no scalar halo cells).  That frees the registers for FOUR own rows per lane at radius
+// 4 and makes every radius up to 8 fit (RJ = 2).
 //
-//   * window    : WJ x WK waves, RJ rows x 64 lane vectors each; LDS holds [2][WJ*RJ + 2*R1][WK*64*VK + 2*HK] cells
-//                 (double-buffered by step parity: ONE barrier per plane step).
+//   * window    : WJ x WK waves, RJ rows x 64 lane vectors each; LDS holds [2][inputs][WJ*RJ + 2*R1][WK*64*VK + 2*HK] cells
+//                 (double-buffered by step parity: ONE barrier per plane step; the writes of step i+1's window overlap the
+//                 arithmetic of step i).
 //   * halo rows : the 2*R1 rows outside the window are dealt over the workgroup's waves (one 16-byte row load per wave and
-//                 step for radius 4 on the 8-wave tile) and requested PF steps before their plane becomes the centre -- by
+//                 step for radius 4 on the 8-wave tile) and requested two steps before their plane becomes the centre -- by
 //                 then the neighbouring workgroup has pulled them through the XCD's L2 as its own rows.
 //   * halo cells: the R2 cells beside the window's rows: one element load per row by the first 2*HK lanes of the
 //                 window's outermost waves (clamped per cell, so ragged rows need nothing special).
@@ -25,6 +30,7 @@
 //     and bounds test folded into the store, ragged rows) is the march kernel's; it shares MarchParams and the launcher.
 //
 // Same semantics as the reference's loop nest (lib/Passes/DataflowLowering.cpp:258-448), same bits as the other kernels.
+// Measurements: profiles/r02_plane.txt; design notes: DESIGN.md section 3.7.
 #pragma once
 #include "apply_march.hpp"
 
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   constexpr bool PHASED = NS <= 10;
   constexpr int UNROLL = PHASED ? NS : PF;
   V ring[NH][NS][RJ];
-  V jh[NHWX];   // my halo-row units and halo cells of plane i+2 while step i computes
+  V jh[NHWX];   // my halo-row units (and kh: the halo cells beside my rows) of plane i+1, in flight while step i-1 computes
   T kh[NH][RJ];
   V pt[NIN][RJ];   // inputs read at the centre only: row r of the next plane is requested as soon as row r has been computed
 
