@@ -305,12 +305,22 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
     const int* cand = RANK == 3 ? cand3 : cand2;
     const int ncand = RANK == 3 ? 7 : 4;
     int64_t best_cost = -1;
-    for (int c = 0; c < ncand; ++c) {
-      const int64_t len = cand[c] < planes ? cand[c] : planes;
+    auto consider = [&](int64_t len) {
+      if (len > planes) len = planes;
       const int64_t blocks = ((planes + len - 1) / len) * tilesJK;
       const int64_t rounds = (blocks + slots - 1) / slots;
       const int64_t cost = rounds * (len + 2 * R0 + TL::PF + 2);
       if (best_cost < 0 || cost < best_cost) { best_cost = cost; chunk = len; }
+    };
+    for (int c = 0; c < ncand; ++c) consider(cand[c]);
+    // ... and the lengths that FILL a whole number of rounds: as many chunks as r rounds hold, planes spread evenly over them
+    // (1025 planes on 132 tiles and 256 slots: 13 chunks of 79 planes = 6.7 rounds of 7, against 11 chunks of 96 = 5.7 of 6)
+    for (int64_t r = 1; r <= 64; ++r) {
+      const int64_t n = r * slots / tilesJK;
+      if (n < 1) continue;
+      const int64_t len = (planes + n - 1) / n;
+      if (len < cand[ncand - 1]) break;
+      if (len <= cand[0]) consider(len);
     }
   }
   if (chunk > planes) chunk = planes;
