@@ -372,7 +372,13 @@ struct PlanesAcc {
     constexpr int oi = PickOffset<3, 0, O...>::value, oj = PickOffset<3, 1, O...>::value, ok = PickOffset<3, 2, O...>::value;
     if constexpr ((HMASK >> IN) & 1u) {
       static_assert(oi >= -R0 && oi <= R0 && oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2, "access outside the declared footprint");
-      return lp[((PH + oi + R0) % NB) * PLANE + (r + oj) * LROW + e + ok];
+      // whole 16-byte vectors only: the cell k0+e+ok lies in my own vector or in a neighbouring lane's, and every tap of a
+      // (plane, row) is served by the same two or three conflict-free ds_read_b128 (element reads at a 16-byte lane stride
+      // are 4-way bank conflicts: ds_read(2)_b32 bank = (address / 4) mod 32)
+      constexpr int VKc = 16 / (int)sizeof(T), q = e + ok;
+      constexpr int vo = q >= 0 ? q / VKc : -((-q + VKc - 1) / VKc);
+      const V vec = *reinterpret_cast<const V*>(lp + ((PH + oi + R0) % NB) * PLANE + (r + oj) * LROW + vo * VKc);
+      return vec[q - vo * VKc];
     } else {
       static_assert(oi == 0 && oj == 0 && ok == 0, "only halo inputs may be read at an offset");
       return pt[IN][r][e];
@@ -549,7 +555,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
         PlanesAcc<T, NIN, FP, RJ, r, e, LROW, PLANE, ph, NB> acc{pt, lp, li, lj, lk};
         const T val = body(acc);
         T through;
-        if constexpr (HMASK & 1u) through = lp[((ph + R0) % NB) * PLANE + r * LROW + e];
+        if constexpr (HMASK & 1u) through = (*reinterpret_cast<const V*>(lp + ((ph + R0) % NB) * PLANE + r * LROW))[e];
         else through = pt[0][r][e];
         res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
@@ -559,7 +565,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
         else *dst = res;
       }
       if constexpr (NIN > 1) load_point_row(i + 1, rc);
-      __builtin_amdgcn_sched_barrier(0);
+      // radius 1 (27 taps): no fence between rows -- adjacent own rows read the same LDS rows, and the compiler may keep them;
+      // radius 2: one row at a time, or the 125 taps' vectors of all rows are live at once
+      if constexpr (R0 > 1 || R1 > 1 || R2 > 1) __builtin_amdgcn_sched_barrier(0);
     });
   };
 
