@@ -303,9 +303,11 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
       return cus * per_cu;
     }();
     constexpr int R0 = (TL::JK2 && RANK == 2) ? 0 : FP::R0;
-    const int cand3[] = {128, 96, 64, 48, 32, 24, 16}, cand2[] = {32, 24, 16, 8};
+    // (up to 512 planes: 1024^3 on the 8-rows-per-lane tile is ONE round of 256 workgroups then, 2.75-2.78 ms against 2.79 with
+    // 256-plane and 2.80 with 128-plane chunks; a 1024-plane chunk leaves half the CUs idle: 3.93 ms)
+    const int cand3[] = {512, 256, 128, 96, 64, 48, 32, 24, 16}, cand2[] = {32, 24, 16, 8};
     const int* cand = RANK == 3 ? cand3 : cand2;
-    const int ncand = RANK == 3 ? 7 : 4;
+    const int ncand = RANK == 3 ? 9 : 4;
     int64_t best_cost = -1;
     auto consider = [&](int64_t len) {
       if (len > planes) len = planes;

@@ -132,13 +132,13 @@ int autotune_launches(L&& launch, bool march_planned, int rank, int nv, hipStrea
   double best_t = time_launches(launch, st, &probe, 2, reps);
   if (best_t < 0) return (int)best_t;
   if (march_planned) {
-    const int chunks3[] = {0, 32, 64, 128, 256}, chunks2[] = {0};
+    const int chunks3[] = {0, 32, 64, 128, 256, 512}, chunks2[] = {0};
     for (int v = 0; v < nv; ++v) {
       const MarchVariant* mv = march_variant(rank, v);   // indices below the caller's count name the same tiles everywhere
       if (!mv) break;
       const bool tile2 = rank == 2 && mv->jk;
       const int* chunks = (rank == 3 || !tile2) ? chunks3 : chunks2;
-      const int nc = (rank == 3 || !tile2) ? 5 : 1;
+      const int nc = (rank == 3 || !tile2) ? 6 : 1;
       for (int c = 0; c < nc; ++c) {
         neptune_hip_launch_cfg_t cfg = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
         const double t = time_launches(launch, st, &cfg, 1, reps);
