@@ -325,7 +325,8 @@ def main():
             op(bufs[s % 2], bufs[(s + 1) % 2])
 
     # Clock ramp: the chip leaves its idle clocks only after some tens of milliseconds of load, which
-    # is longer than the whole run of the small workloads (512^3: 0.2-0.4 ms per step).  Spend ~0.3 s
+    # is longer than the whole run of the small workloads (512^3: 0.2-0.4 ms per step).  Spend ~1 s (0.3 s was not
+    # enough for the first process on a fresh box: the 27-point workload then read 0.23-0.29 ms instead of 0.19)
     # of untimed steps first, then restore the initial fields so the W warm-up steps and the K timed
     # steps start from the same data whatever the ramp did.
     # The stencil iterations are not contractive (27-point fp32: values grow ~52x per step), so the fields are
@@ -340,7 +341,7 @@ def main():
         bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
         torch.cuda.synchronize()
         n_ramp += 10
-        go = time.perf_counter() - t_ramp < 0.3 and n_ramp < 2000
+        go = time.perf_counter() - t_ramp < 1.0 and n_ramp < 6000
         if world > 1:   # every rank must run the same number of steps (each step is an exchange): rank 0 decides
             flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=coll_dev)
             dist.broadcast(flag, 0)
