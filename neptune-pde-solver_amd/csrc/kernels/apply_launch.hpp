@@ -252,22 +252,32 @@ constexpr bool plane_only() {
   return (plane_capable<FP, RANK>() && (FP::R0 > 4 || FP::R1 > 4 || FP::R2 > 4 || (NH > 1 && wide) || NH > 2)) ||
          (planes_capable<T, FP, RANK>() && (FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1));
 }
+// rank 2: footprints beyond the march kernel's registers (stars beyond radius 4 or a K radius beyond two lane vectors, boxes beyond
+// radius 2, several inputs read at wide offsets) run the LDS tile kernel (neptune_apply_tile2) on every row
+template <class T, class FP, int RANK>
+constexpr bool tile2_only() {
+  constexpr int VK = 16 / (int)sizeof(T), NH = popcount_u(FP::HALO_MASK), rbig = FP::R0 > FP::R2 ? FP::R0 : FP::R2;
+  return tile2_capable<T, FP, RANK>() &&
+         ((!FP::BOX && (FP::R0 > 4 || FP::R2 > 4 || FP::R2 > 2 * VK)) || (FP::BOX && rbig > 2) || (NH > 1 && (rbig > 2 || (FP::BOX && rbig > 1))));
+}
 template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT, int PF, bool NTL, bool LDSJ, bool JK, bool JHL, int KD, bool PLN>
 struct TileFor {
-  static constexpr bool star = plane_capable<FP, RANK>(), box = planes_capable<T, FP, RANK>();
-  static constexpr bool pln = (star || box) && (PLN || plane_only<T, FP, RANK>());
+  static constexpr bool star = plane_capable<FP, RANK>(), box = planes_capable<T, FP, RANK>(), flat = tile2_only<T, FP, RANK>();
+  static constexpr bool pln = flat || ((star || box) && (PLN || plane_only<T, FP, RANK>()));
   // a march row that only lands here because nothing else can hold the footprint becomes one of TWO plane tiles (the 8-wave
   // default, or the 4-wave one for the small-field rows): eight different plane kernels per apply would only cost compile time
   static constexpr bool canon = pln && !PLN;
-  static constexpr int wj = canon ? (WJ * WK <= 4 ? 4 : 8) : WJ, wk = canon ? 1 : WK, rj = canon ? 4 : RJ;
-  static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : star ? plane_rows<T, FP>(rj, wj, wk) : planes_rows<T, FP>(rj, wj, wk);
-  using type = std::conditional_t<canon, Tile<rows, wj, 1, true, true, 1, false, true, false, true, 1, true>,
-                                  Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>>;
+  static constexpr int wj = flat ? 8 : canon ? (WJ * WK <= 4 ? 4 : 8) : WJ, wk = (canon || flat) ? 1 : WK, rj = (canon || flat) ? 4 : RJ;
+  static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : flat ? tile2_rows<T, FP>(rj, wj, wk) : star ? plane_rows<T, FP>(rj, wj, wk) : planes_rows<T, FP>(rj, wj, wk);
+  using type = std::conditional_t<flat, Tile<rows, 8, 1, true, true, 1, false, true, true, true, 1, true>,
+               std::conditional_t<canon, Tile<rows, wj, 1, true, true, 1, false, true, false, true, 1, true>,
+                                  Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>>>;
 };
 // star footprints: the centre plane in LDS, the ring of own cells in registers; box footprints: every live plane in LDS
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
 constexpr auto march_kernel_fn() {
-  if constexpr (TL::PLN && FP::BOX) return &neptune_apply_planes<Body, T, NIN, FP, TL>;
+  if constexpr (TL::PLN && RANK == 2) return &neptune_apply_tile2<Body, T, NIN, FP, TL>;
+  else if constexpr (TL::PLN && FP::BOX) return &neptune_apply_planes<Body, T, NIN, FP, TL>;
   else if constexpr (TL::PLN) return &neptune_apply_plane<Body, T, NIN, FP, TL>;
   else return &neptune_apply_march<Body, T, RANK, NIN, FP, TL>;
 }
@@ -400,6 +410,11 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
     ok = ok && ((uintptr_t)in[k] % 16 == 0);
   }
   ok = ok && ((uintptr_t)out % 16 == 0);
+  if constexpr (RANK == 2) {
+    // the LDS tile kernel keeps in-plane offsets in 32 bits and has no march form to fall back on
+    if (tile2_only<T, FP, RANK>())
+      ok = ok && (g->out_ub[0] - g->out_lb[0]) * (g->out_ub[1] - g->out_lb[1]) * (int64_t)sizeof(T) < 0x7fffffffLL;
+  }
   for (int d = (RANK == 1 ? 0 : 1); ok && d < RANK; ++d)  // rank 1 has no marched dim to restrict
     ok = ok && g->region_lb[d] == 0 && g->region_ub[d] == g->out_ub[d] - g->out_lb[d];
   if (want == NEPTUNE_HIP_KERNEL_MARCH) return ok ? NEPTUNE_HIP_KERNEL_MARCH : NEPTUNE_HIP_EUNSUPPORTED;
@@ -568,7 +583,8 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     int variant = pick_march_variant<T, RANK, FP>(g, cfg);
     if (RANK == 3 && variant == 6 && !(cfg && cfg->variant == 6) && march3_variant_scratch<Body, T, RANK, NIN, FP>(6) > 0)
       variant = 4;  // automatic choice only: this body spills on the 8-rows-per-lane tile
-    const bool jk = RANK == 2 && march_variant(RANK, variant)->jk;  // rank-2 tile form: (d0,d1) -> (J,K), one plane
+    // rank-2 tile form: (d0,d1) -> (J,K), one plane (the LDS tile kernel is a tile form whatever the table row says)
+    const bool jk = RANK == 2 && (march_variant(RANK, variant)->jk || tile2_only<T, FP, RANK>());
     auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
       if (jk) { dst[0] = fill; dst[1] = src[0]; dst[2] = src[1]; }
       else to_axes<RANK>(src, dst, fill);

@@ -580,4 +580,189 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
   }
 }
 
+// ---- RANK 2: the window of a tile in LDS ---------------------------------------------------------------------------
+// 2-D footprints beyond what the march kernel's registers hold -- stars beyond radius 4, boxes beyond radius 2 (7x7, 9x9
+// windows), several wide halo inputs -- in the shape of the rank-2 tile form (apply_march.hpp, Tile::JK2): the field is ONE
+// plane tiled in (rows, columns), a workgroup loads its window once, computes and retires.  Here the whole window of every
+// input read at offsets -- own rows, the R rows above and below, the halo cells and the corners -- goes to LDS and every
+// tap is served from whole 16-byte LDS vectors (as in neptune_apply_planes); registers hold nothing but the loads in flight.
+// (d0, d1) -> (J, K): FP::R0 is the row radius, FP::R2 the column radius.
+template <class T, class FP, int RANK>
+constexpr bool tile2_capable() {
+  return RANK == 2 && FP::MARCH_OK && popcount_u(FP::HALO_MASK) >= 1 && FP::R0 <= 8 && FP::R2 <= 8;
+}
+template <class T, class FP>
+constexpr int tile2_rows(int rj, int wj, int wk) {
+  constexpr int VK = 16 / (int)sizeof(T), HK = (FP::R2 + VK - 1) / VK * VK, NH = popcount_u(FP::HALO_MASK);
+  while (rj > 1 && NH * (wj * rj + 2 * FP::R0) * (wk * kWave * VK + 2 * HK) * (int)sizeof(T) > 64 * 1024) rj /= 2;   // two workgroups per CU
+  return rj;
+}
+
+template <class T, int NIN, class FP, int RJ, int r, int e, int LROW, int WIN>
+struct Tile2Acc {
+  static constexpr int R1 = FP::R0, R2 = FP::R2, VK = 16 / (int)sizeof(T);
+  static constexpr unsigned HMASK = FP::HALO_MASK;
+  using V = typename Vec16<T>::type;
+  const V (&pt)[NIN][RJ];
+  const T* lp;         // LDS: this lane's cell (own row 0, element 0) in the window of halo input 0
+  int64_t lj, lk;
+
+  template <int IN, int... O>
+  __device__ __forceinline__ T get() const {
+    static_assert(IN >= 0 && IN < NIN, "input index out of range");
+    constexpr int oj = PickOffset<2, 0, O...>::value, ok = PickOffset<2, 1, O...>::value;
+    if constexpr ((HMASK >> IN) & 1u) {
+      static_assert(oj >= -R1 && oj <= R1 && ok >= -R2 && ok <= R2, "access outside the declared footprint");
+      static_assert(FP::BOX || (oj != 0) + (ok != 0) <= 1, "star footprint declared but a diagonal access is used");
+      constexpr int h = halo_slot(HMASK, IN), q = e + ok;
+      constexpr int vo = q >= 0 ? q / VK : -((-q + VK - 1) / VK);
+      const V vec = *reinterpret_cast<const V*>(lp + h * WIN + (r + oj) * LROW + vo * VK);
+      return vec[q - vo * VK];
+    } else {
+      static_assert(oj == 0 && ok == 0, "only halo inputs may be read at an offset");
+      return pt[IN][r][e];
+    }
+  }
+  template <int D>
+  __device__ __forceinline__ int64_t idx() const {
+    static_assert(D >= 0 && D < 2, "index argument out of range");
+    return D == 0 ? lj : lk;
+  }
+};
+
+template <class Body, class T, int NIN, class FP, class TL>
+__global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(MarchParams<T, NIN> P, Body body) {
+  constexpr int RJ = TL::RJ, WJ = TL::WJ, WK = TL::WK, NW = WJ * WK;
+  constexpr bool NT = TL::NT;
+  using V = typename Vec16<T>::type;
+  constexpr int VK = 16 / sizeof(T);
+  constexpr int R1 = FP::R0, R2 = FP::R2;
+  constexpr unsigned HMASK = FP::HALO_MASK;
+  constexpr int NH = popcount_u(HMASK);
+  static_assert(NH >= 1, "tile kernel: at least one input read at offsets");
+  constexpr int HK = (R2 + VK - 1) / VK * VK;
+  constexpr int TJ = WJ * RJ, SPAN = kWave * VK, TK = WK * SPAN;
+  constexpr int LROW = TK + 2 * HK, LR = TJ + 2 * R1, WIN = LR * LROW;
+  constexpr int NU = 2 * R1 * WK, NUA = NH * NU;
+  constexpr int NHW = NUA ? (NUA + NW - 1) / NW : 0, NHWX = NHW ? NHW : 1;
+  static_assert(2 * HK <= kWave, "K halo cells are loaded by the first 2*HK lanes");
+  static_assert(NH * WIN * (int)sizeof(T) <= 160 * 1024, "windows do not fit the LDS");
+  __shared__ __attribute__((aligned(16))) T lds[NH][LR][LROW];
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wj = w / WK, wk = w % WK;
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t kt = v % P.nK, jt = v / P.nK;
+  const int32_t j0w = P.rJ0 + (int32_t)(jt * TJ);
+  const int32_t j0 = j0w + wj * RJ;
+  const int32_t kw0 = (int32_t)(kt * (uint32_t)TK);
+  const int32_t kw = kw0 + wk * SPAN;
+  const int32_t k0 = kw + lane * VK;
+  const bool lane_ok = k0 < P.Ks;
+  const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
+
+  auto row_bytes = [&](int32_t j) -> uint32_t {
+    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  };
+  auto cell_bytes = [&](int32_t k) -> uint32_t {
+    k = k < 0 ? 0 : (k >= P.N2 ? P.N2 - 1 : k);
+    return (uint32_t)k * (uint32_t)sizeof(T);
+  };
+  const bool c_left = lane < HK, c_right = lane >= HK && lane < 2 * HK;
+  const uint32_t cell_b = cell_bytes(c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK));
+  const int32_t cell_col = c_left ? lane : HK + TK + (lane - HK);
+  const bool kh_any = R2 > 0 && ((wk == 0 && c_left) || (wk == WK - 1 && c_right));
+  const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;
+  T* buf = &lds[0][0][0];
+
+  // ---- load the window: my own rows and the halo cells beside them (every input read at offsets), my halo-row units with
+  // their corner cells; everything is requested before the first LDS write
+  V own[NH][RJ];
+  T kh[NH][RJ];
+  V jh[NHWX];
+  T hc[NHWX];
+  V pt[NIN][RJ];
+  int32_t hdst[NHWX], hcdst[NHWX];
+  bool hc_any[NHWX];
+  static_for<NH>([&](auto hcn) {
+    constexpr int h = hcn;
+    const char* base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, h)]);
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      const uint32_t rb = row_bytes(j0 + r);
+      own[h][r] = *reinterpret_cast<const V*>(base + (rb + lane_b));
+      if constexpr (R2 > 0) { if (kh_any) kh[h][r] = *reinterpret_cast<const T*>(base + (rb + cell_b)); }
+    });
+  });
+  static_for<NHW>([&](auto tc) {
+    constexpr int tt = tc;
+    const int uu = w + tt * NW;
+    const int hh = NU ? uu / NU : 0, u = NU ? uu % NU : 0;
+    const int x = u / WK, sp = u % WK;
+    const int32_t kc = kw0 + sp * SPAN + lane * VK;
+    const uint32_t rb = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
+    const int32_t lrow = hh * WIN + (x < R1 ? x : TJ + x) * LROW;
+    hdst[tt] = uu < NUA ? lrow + HK + sp * SPAN + lane * VK : -1;
+    hcdst[tt] = lrow + cell_col;
+    hc_any[tt] = FP::BOX && R2 > 0 && uu < NUA && ((sp == 0 && c_left) || (sp == WK - 1 && c_right));
+    const T* field = P.in[halo_input_of(HMASK, 0)];
+    static_for<NH>([&](auto hcn) { constexpr int h = hcn; if (hh == h) field = P.in[halo_input_of(HMASK, h)]; });
+    const char* base = reinterpret_cast<const char*>(field);
+    if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(base + (rb + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T)));
+    if (hc_any[tt]) hc[tt] = *reinterpret_cast<const T*>(base + (rb + cell_b));
+  });
+  static_for<NIN>([&](auto nc) {
+    constexpr int n = nc;
+    if constexpr (!((HMASK >> n) & 1u)) {
+      const char* base = reinterpret_cast<const char*>(P.in[n]);
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = *reinterpret_cast<const V*>(base + (row_bytes(j0 + r) + lane_b)); });
+    }
+  });
+
+  // ---- lay it out, one barrier, compute
+  static_for<NH>([&](auto hcn) {
+    constexpr int h = hcn;
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) = own[h][r];
+      if constexpr (R2 > 0) { if (kh_any) buf[h * WIN + (R1 + wj * RJ + r) * LROW + cell_col] = kh[h][r]; }
+    });
+  });
+  static_for<NHW>([&](auto tc) {
+    constexpr int tt = tc;
+    if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[tt];
+    if (hc_any[tt]) buf[hcdst[tt]] = hc[tt];
+  });
+  __syncthreads();
+
+  const T* lp = buf + own_cell;
+  char* obase = reinterpret_cast<char*>(P.out);
+  static_for<RJ>([&](auto rc) {
+    constexpr int r = rc;
+    const int32_t j = j0 + r;
+    const int64_t lj = (int64_t)j + P.olb[1];
+    const bool in_j = j >= P.plb[1] && j < P.pub[1];
+    V res;
+    static_for<VK>([&](auto ec) {
+      constexpr int e = ec;
+      const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
+      const bool inside = in_j && (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
+      Tile2Acc<T, NIN, FP, RJ, r, e, LROW, WIN> acc{pt, lp, lj, lk};
+      const T val = body(acc);
+      T through;
+      if constexpr (HMASK & 1u) through = own[0][r][e];   // input 0 owns window 0
+      else through = pt[0][r][e];
+      res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
+    });
+    if (j < P.rJ1 && lane_ok) {
+      V* dst = reinterpret_cast<V*>(obase + (row_bytes(j) + lane_b));
+      if constexpr (NT) __builtin_nontemporal_store(res, dst);
+      else *dst = res;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
 }  // namespace neptune_hip

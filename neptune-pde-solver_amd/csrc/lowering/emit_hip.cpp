@@ -309,6 +309,9 @@ struct Emitter {
     if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs >= 2 && rbig <= 8 && (R[1] > 0 || R[2] > 0) &&
         fp.halo_inputs * (2 * std::max(R[0], 1) + 2) <= 21)
       fp.march_ok = true;
+    // 2-D footprints beyond that, up to radius 8 (stars and boxes, up to four inputs read at offsets): the window of a tile in
+    // LDS (neptune_apply_tile2)
+    if (!fp.march_ok && rank == 2 && fp.halo_inputs >= 1 && fp.halo_inputs <= 4 && rbig <= 8) fp.march_ok = true;
     // 3-D boxes of one halo input up to radius 2 (125 points): every live plane in LDS (neptune_apply_planes)
     if (!fp.march_ok && rank == 3 && fp.box && fp.halo_inputs == 1 && rbig <= 2 && R[0] >= 1) fp.march_ok = true;
     if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }

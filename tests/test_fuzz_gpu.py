@@ -202,7 +202,7 @@ def test_random_applies_match_the_oracle(env, monkeypatch, seed):
         d_ins = [torch.from_numpy(a).cuda() for a in ins]
         settings = [{}, {"NEPTUNE_HIP_KERNEL": "direct"}, {"NEPTUNE_HIP_KERNEL": "direct-flat"}]
         if kern[name] == "march":
-            nvar = {3: 7, 2: 3, 1: 1}[rank]
+            nvar = {3: 8, 2: 3, 1: 1}[rank]
             settings += [{"NEPTUNE_HIP_KERNEL": "march", "NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": "3"} for v in range(nvar)]
         for s in settings:
             for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):

@@ -293,7 +293,8 @@ def test_footprint_limits_of_the_march_kernel():
     box3 = [(0, (a, b, c)) for a in (-3, 0, 3) for b in (-1, 1) for c in (-2, 2)]
     assert kernel_of((16, 16, 128), "f64", box3, 3)[0] == "direct"
     box2 = [(0, (a, b)) for a in range(-3, 4) for b in (-3, 3)]
-    assert kernel_of((32, 256), "f64", box2, 3)[0] == "direct"
+    assert kernel_of((32, 256), "f64", box2, 3)[0] == "march"          # 2-D beyond radius 2 / 4: the LDS tile kernel, up to radius 8
+    assert kernel_of((40, 256), "f64", [(0, o) for o in mh.star(2, 9) if max(map(abs, o)) in (0, 9)], 9)[0] == "direct"
 
 
 def test_every_apply_gets_a_geometry_level_entry():

@@ -108,15 +108,20 @@ CASES = {
     "radius4_2d_f32": ((28, 512), "f32", 1, [(0, o) for o in star(2, 4)], 4, "march"),
     "radius4_1d": ((5000,), "f64", 1, [(0, o) for o in star(1, 4)], 4, "march"),
     "radius8_1d_f32": ((3000,), "f32", 1, [(0, o) for o in star(1, 8)], 8, "march"),
-    "radius3_pair_2d": ((26, 256), "f64", 2, [(0, o) for o in star(2, 3)] + [(1, o) for o in star(2, 3)[1:]], 3, "direct"),
-    "radius5_2d": ((30, 256), "f64", 1, [(0, o) for o in star(2, 5)], 5, "direct"),
+    "radius3_pair_2d": ((26, 256), "f64", 2, [(0, o) for o in star(2, 3)] + [(1, o) for o in star(2, 3)[1:]], 3, "march"),
+    "radius5_2d": ((30, 256), "f64", 1, [(0, o) for o in star(2, 5)], 5, "march"),
+    # 2-D footprints beyond the march kernel's registers: the window of a tile in LDS (neptune_apply_tile2)
+    "radius8_2d_f32_ragged": ((47, 771), "f32", 1, [(0, o) for o in star(2, 8)], 8, "march"),
+    "box49_2d": ((40, 258), "f64", 1, [(0, (a, b)) for a in range(-3, 4) for b in range(-3, 4)], 3, "march"),
+    "box_radius4_sparse_2d_f32": ((35, 512), "f32", 2, [(1, (a, b)) for a in (-4, -1, 0, 3) for b in (-4, 0, 2, 4)] + [(0, (0, 0))], 4, "march"),
+    "four_radius3_2d": ((33, 384), "f64", 4, [(k, o) for k in range(4) for o in star(2, 3)[k:9 + k]], 3, "march"),
     "pair_1d": ((4096,), "f64", 2, [(0, (0,)), (0, (-1,)), (0, (1,)), (1, (1,)), (1, (-1,)), (1, (0,))], 1, "march"),
     "pair_1d_f32_r2": ((2048,), "f32", 2, [(0, (0,)), (0, (-2,)), (1, (2,)), (1, (-1,))], 2, "march"),
     # radius 2 with two halo inputs in 3-D exceeds the register budget: the lowering picks the direct kernel
     # 2-D 25-point box (5x5 window): K halos for every ring row, two-row LDS exchange with corners
     "box25_2d": ((30, 256), "f64", 1, [(0, (a, b)) for a in range(-2, 3) for b in range(-2, 3)], 2, "march"),
     "box25_2d_f32_ragged": ((29, 515), "f32", 1, [(0, (a, b)) for a in range(-2, 3) for b in range(-2, 3) if (a + b) % 3], 2, "march"),
-    "box25_pair_2d": ((20, 256), "f64", 2, [(k, (a, b)) for k in range(2) for a in (-2, 0, 2) for b in (-2, 1)], 2, "direct"),
+    "box25_pair_2d": ((20, 256), "f64", 2, [(k, (a, b)) for k in range(2) for a in (-2, 0, 2) for b in (-2, 1)], 2, "march"),
     "radius3_3d": ((14, 18, 256), "f64", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius3_3d_f32_ragged": ((13, 17, 261), "f32", 1, [(0, o) for o in star(3, 3)], 3, "march"),
     "radius4_3d": ((12, 14, 128), "f64", 1, [(0, o) for o in star(3, 4)], 4, "march"),

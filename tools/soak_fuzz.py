@@ -37,7 +37,7 @@ def main():
             d_ins = [torch.from_numpy(a).cuda() for a in ins]
             settings = [{}, {"NEPTUNE_HIP_KERNEL": "direct"}, {"NEPTUNE_HIP_KERNEL": "direct-flat"}]
             if kern[name] == "march":
-                nvar = {3: 7, 2: 3, 1: 1}[len(shape)]
+                nvar = {3: 8, 2: 3, 1: 1}[len(shape)]
                 settings += [{"NEPTUNE_HIP_KERNEL": "march", "NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c}
                              for v in range(nvar) for c in ("1", "5")]
             for s in settings:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-off soak of the plane-in-LDS kernels (csrc/kernels/apply_plane.hpp): random 3-D stars of radius 2..8 (unequal radii
+"""One-off soak of the plane-in-LDS kernels (csrc/kernels/apply_plane.hpp; every fifth seed: the rank-2 LDS tile kernel): random 3-D stars of radius 2..8 (unequal radii
 per axis, optional second input read at the centre) and random radius-2 boxes, random field shapes (windows and chunks
 cut inside the field, ragged rows), tight bounds; every default tile x chunk seams + the direct kernel, bit for bit against
 the oracle.  Modules are compiled by a pool of host threads.      usage: tools/soak_plane.py FIRST_SEED COUNT [THREADS]"""
@@ -22,6 +22,8 @@ def gen_case(seed):
     rng = np.random.default_rng(seed)
     elem = str(rng.choice(["f64", "f64", "f32"]))
     vk = 2 if elem == "f64" else 4
+    if seed % 5 == 4:
+        return gen_case_2d(rng, elem, vk)
     box = rng.random() < 0.25
     if box:
         rad = [int(rng.integers(1, 3)), int(rng.integers(0, 3)), int(rng.integers(0, 3))]
@@ -67,6 +69,44 @@ def gen_case(seed):
     return text, shape, elem, nin, rad, box
 
 
+def gen_case_2d(rng, elem, vk):
+    """rank 2, beyond the march kernel's registers: the LDS tile kernel (neptune_apply_tile2)"""
+    import test_multihalo_gpu as mh
+    kind = str(rng.choice(["star", "box", "multi"]))
+    nin = 1
+    if kind == "star":
+        rad = [int(rng.integers(5, 9)), int(rng.integers(0, 9))] if rng.random() < 0.5 else [int(rng.integers(0, 9)), int(rng.integers(5, 9))]
+        taps = [(0, 0)] + [tuple(sg * dist if a == d else 0 for a in range(2)) for d in range(2) for sg in (-1, 1)
+                           for dist in range(1, rad[d] + 1) if dist == rad[d] or rng.random() < 0.7]
+        accesses = [(0, o) for o in taps]
+    elif kind == "box":
+        rad = [int(rng.integers(1, 5)), int(rng.integers(1, 5))]
+        rad[int(rng.integers(0, 2))] = int(rng.integers(3, 5))
+        taps = {(0, 0), (rad[0], -rad[1]), (-rad[0], rad[1])}
+        for _ in range(int(rng.integers(6, 50))):
+            taps.add((int(rng.integers(-rad[0], rad[0] + 1)), int(rng.integers(-rad[1], rad[1] + 1))))
+        accesses = [(0, o) for o in sorted(taps)]
+    else:
+        nin = int(rng.integers(2, 5))
+        rad = [int(rng.integers(3, 6)), int(rng.integers(1, 6))]
+        accesses = [(0, (0, 0))]
+        for k in range(nin):
+            for d in range(2):
+                for sg in (-1, 1):
+                    accesses.append((k, tuple(sg * rad[d] if a == d else 0 for a in range(2))))
+                    if rad[d] > 1 and rng.random() < 0.5:
+                        accesses.append((k, tuple(sg * int(rng.integers(1, rad[d])) if a == d else 0 for a in range(2))))
+        accesses = list(dict.fromkeys(accesses))
+    accesses = accesses[:len(mh.COEF)]
+    n0 = 2 * rad[0] + int(rng.choice([3, 9, 30, 41, 70]))
+    n1 = int(rng.choice([128, 192, 256, 320, 520])) * (vk // 2) + (int(rng.integers(1, vk)) if rng.random() < 0.4 else 0)
+    n1 = max(n1, 64 * vk + 2 * rad[1] + 2 * vk)
+    shape = (n0, n1)
+    lb = [rad[d] + int(rng.integers(0, 2)) for d in range(2)]
+    ub = [shape[d] - rad[d] - int(rng.integers(0, 2)) for d in range(2)]
+    return mh.module_text(shape, elem, nin, accesses, lb, ub), shape, elem, nin, rad, kind != "star"
+
+
 def main():
     first, count = int(sys.argv[1]), int(sys.argv[2])
     threads = int(sys.argv[3]) if len(sys.argv) > 3 else 8
@@ -92,7 +132,8 @@ def main():
             d_ins = [torch.from_numpy(a).cuda() for a in ins]
             settings = [{}, {"NEPTUNE_HIP_KERNEL": "direct"}]
             if kern == "march":
-                settings += [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c} for v in range(8) for c in ("1", "3", "0")]
+                nvar = 8 if len(shape) == 3 else 3
+                settings += [{"NEPTUNE_HIP_VARIANT": str(v), "NEPTUNE_HIP_CHUNK": c} for v in range(nvar) for c in ("1", "3", "0")]
             for s in settings:
                 for k in ("NEPTUNE_HIP_KERNEL", "NEPTUNE_HIP_VARIANT", "NEPTUNE_HIP_CHUNK"):
                     os.environ.pop(k, None)
