@@ -57,6 +57,29 @@ typedef struct {
   int64_t sizes[3];
   int64_t strides[3];
 } NeptuneMemRef3D;
+/* rank 4..6 (fields with leading batch / component dimensions: the lowering peels them off and launches one rank-3
+ * apply per leading index, see neptune-pde-solver_amd/csrc/runtime/lowered_runtime.hpp run_apply_batched) */
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[4];
+  int64_t strides[4];
+} NeptuneMemRef4D;
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[5];
+  int64_t strides[5];
+} NeptuneMemRef5D;
+typedef struct {
+  void *allocated;
+  void *aligned;
+  int64_t offset;
+  int64_t sizes[6];
+  int64_t strides[6];
+} NeptuneMemRef6D;
 
 /* ------------------------------------------------------------------------------------
  * 2. constants

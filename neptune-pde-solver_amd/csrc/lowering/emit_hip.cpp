@@ -73,9 +73,9 @@ std::string float_literal(const std::string& lit, const std::string& elem, bool&
 std::string box_init(const Bounds& b) {
   std::ostringstream o;
   o << "{" << b.rank() << ", {";
-  for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.lb[d] : 0);
+  for (int d = 0; d < 6; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.lb[d] : 0);
   o << "}, {";
-  for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.ub[d] : 1);
+  for (int d = 0; d < 6; ++d) o << (d ? ", " : "") << (d < b.rank() ? b.ub[d] : 1);
   o << "}}";
   return o.str();
 }
@@ -90,6 +90,7 @@ struct Footprint {
   int halo_inputs = 0;
   int R[3] = {0, 0, 0};  // shared radii on the kernel's (I,J,K) axes
   bool march_ok = true;
+  int lead = 0;          // leading (batch / component) dimensions of an apply of rank 4..6: peeled off on the host
   bool exact = true;     // no elementary functions in the body
 };
 
@@ -116,7 +117,7 @@ struct Emitter {
         const int k = temp_index.at(op->operands[0]);
         int nz = 0;
         for (int d = 0; d < fp.rank; ++d) {
-          const int a = (int)std::llabs(op->offsets[d]);
+          const int a = (int)std::llabs(op->offsets[fp.lead + d]);
           if (a) ++nz;
           if (a > fp.radius[k][d]) fp.radius[k][d] = a;
           if (top && a > fp.top_radius[k][d]) fp.top_radius[k][d] = a;  // starts at -1: offset 0 counts
@@ -143,13 +144,14 @@ struct Emitter {
       const std::string& n = op.name;
       auto val = [&](const std::string& v) -> std::string {
         auto it = index_arg.find(v);
-        if (it != index_arg.end()) return "a.template idx<" + std::to_string(it->second) + ">()";
+        if (it != index_arg.end())
+          return it->second < 0 ? "lead[" + std::to_string(-it->second - 1) + "]" : "a.template idx<" + std::to_string(it->second) + ">()";
         return cname(v);
       };
       auto res = [&]() { return cname(op.results.at(0)); };
       if (n == "neptune_ir.access") {
         o << ind << "const " << ctype(op.types[1].elem) << " " << res() << " = a.template get<" << temp_index.at(op.operands[0]);
-        for (auto off : op.offsets) o << ", " << off;
+        for (size_t d = op.offsets.size() > 3 ? op.offsets.size() - 3 : 0; d < op.offsets.size(); ++d) o << ", " << op.offsets[d];
         o << ">();\n";
       } else if (n == "arith.constant") {
         const Type& t = op.types[0];
@@ -256,35 +258,58 @@ struct Emitter {
     const int rank = b.rank();
     const int nin = (int)apply.operands.size();
     const Type& res = apply.types[nin];
-    if (rank > 3) { diag.fail(apply.line, "apply of rank " + std::to_string(rank) + " (the HIP backend supports rank 1..3)"); return false; }
+    if (rank > 6) { diag.fail(apply.line, "apply of rank " + std::to_string(rank) + " (the HIP backend supports rank 1..6)"); return false; }
     if (nin > 4) { diag.fail(apply.line, "apply with more than 4 inputs"); return false; }
     if (res.elem != "f64" && res.elem != "f32") { diag.fail(apply.line, "apply element type " + res.elem + " (f64 and f32 are supported)"); return false; }
     for (int k = 0; k < nin; ++k)
       if (apply.types[k].elem != res.elem) { diag.fail(apply.line, "apply inputs of mixed element types"); return false; }
     fp = Footprint();
     fp.nin = nin;
-    fp.rank = rank;
+    // rank 4..6: the leading rank-3 dimensions are batch / component dimensions -- no access may have an offset along them
+    // (the kernels are rank 1..3); the host launches one rank-3 apply per leading index (run_apply_batched) and the body
+    // sees the leading indices as members.  Index argument d maps to -(d+1) for a leading dimension.
+    const int lead = rank > 3 ? rank - 3 : 0;
+    fp.lead = lead;
+    fp.rank = rank - lead;
     for (int k = 0; k < 4; ++k)
       for (int d = 0; d < 3; ++d) { fp.radius[k][d] = 0; fp.top_radius[k][d] = -1; }
-    for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d;
+    for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d < lead ? -(d + 1) : d - lead;
     for (int k = 0; k < nin; ++k) temp_index[blk.args[rank + k].name] = k;
+    if (lead > 0) {
+      std::function<bool(const Block&)> no_lead_offsets = [&](const Block& b) -> bool {
+        for (auto& op : b.ops) {
+          if (op->name == "neptune_ir.access")
+            for (int d = 0; d < lead; ++d)
+              if (op->offsets[d] != 0) {
+                diag.fail(op->line, "access with an offset along a leading dimension of a rank-" + std::to_string(rank) +
+                                        " apply (only the last three dimensions may carry offsets)");
+                return false;
+              }
+          for (auto& r : op->regions)
+            if (!no_lead_offsets(*r)) return false;
+        }
+        return true;
+      };
+      if (!no_lead_offsets(blk)) return false;
+    }
     // inputs never read unconditionally keep top_radius -1 ("not accessed": nothing to check)
     scan_accesses(blk, temp_index, fp, true);
     // rank mapping onto the kernel's (I,J,K) axes, see apply_common.hpp AxisMap.
     // every input read at a non-zero offset gets a register ring in the march kernel; the rings share
     // the largest radii
+    const int krank = fp.rank;   // the kernel's rank (the last three dimensions of a wider apply)
     int* R = fp.R;
     for (int k = 0; k < nin; ++k) {
       bool any = false;
-      for (int d = 0; d < rank; ++d) any = any || fp.radius[k][d] > 0;
+      for (int d = 0; d < krank; ++d) any = any || fp.radius[k][d] > 0;
       if (!any) continue;
       ++fp.halo_inputs;
       fp.halo_mask |= 1u << k;
       if (fp.halo_input < 0) fp.halo_input = k;
       const int* r = fp.radius[k];
       int m[3] = {0, 0, 0};
-      if (rank == 3) { m[0] = r[0]; m[1] = r[1]; m[2] = r[2]; }
-      else if (rank == 2) { m[0] = r[0]; m[2] = r[1]; }
+      if (fp.rank == 3) { m[0] = r[0]; m[1] = r[1]; m[2] = r[2]; }
+      else if (fp.rank == 2) { m[0] = r[0]; m[2] = r[1]; }
       else { m[2] = r[0]; }
       for (int a = 0; a < 3; ++a) R[a] = std::max(R[a], m[a]);
     }
@@ -297,23 +322,23 @@ struct Emitter {
     // vector come through a second wave shift, so the K radius may reach two vectors), up to four halo inputs
     // (one beyond radius 2: the register rings of two wide inputs leave one wave per SIMD), boxes up to radius 2
     // (5x5 windows, one halo input).  Wider footprints use the direct kernel.
-    const int rmax = fp.box ? (rank == 3 ? 1 : 2) : 4;
+    const int rmax = fp.box ? (krank == 3 ? 1 : 2) : 4;
     const int rbig = std::max(R[0], std::max(R[1], R[2]));
-    const int hmax = rank == 3 ? (rbig > 1 ? 1 : 2) : ((rbig > 2 || (fp.box && rbig > 1)) ? 1 : 4);
-    fp.march_ok = fp.halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= (rank == 3 ? rmax : 2 * vk) && R[2] <= 2 * vk;
+    const int hmax = krank == 3 ? (rbig > 1 ? 1 : 2) : ((rbig > 2 || (fp.box && rbig > 1)) ? 1 : 4);
+    fp.march_ok = fp.halo_inputs <= hmax && R[0] <= rmax && R[1] <= rmax && R[2] <= (krank == 3 ? rmax : 2 * vk) && R[2] <= 2 * vk;
     // 3-D stars of one halo input beyond that, up to radius 8 (10th- to 16th-order operators): the plane-in-LDS kernel
     // (apply_plane.hpp) keeps only the ring of own cells in registers and reads J / K neighbours from the centre plane in LDS
-    if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs == 1 && rbig <= 8) fp.march_ok = true;
+    if (!fp.march_ok && krank == 3 && !fp.box && fp.halo_inputs == 1 && rbig <= 8) fp.march_ok = true;
     // ... and several inputs read at offsets, a ring and an LDS window each, while two rows per lane of all rings fit the
     // registers: inputs * (2*max(R0,1)+2) <= 21 (apply_plane.hpp plane_capable)
-    if (!fp.march_ok && rank == 3 && !fp.box && fp.halo_inputs >= 2 && rbig <= 8 && (R[1] > 0 || R[2] > 0) &&
+    if (!fp.march_ok && krank == 3 && !fp.box && fp.halo_inputs >= 2 && rbig <= 8 && (R[1] > 0 || R[2] > 0) &&
         fp.halo_inputs * (2 * std::max(R[0], 1) + 2) <= 21)
       fp.march_ok = true;
     // 2-D footprints beyond that, up to radius 8 (stars and boxes, up to four inputs read at offsets): the window of a tile in
     // LDS (neptune_apply_tile2)
-    if (!fp.march_ok && rank == 2 && fp.halo_inputs >= 1 && fp.halo_inputs <= 4 && rbig <= 8) fp.march_ok = true;
+    if (!fp.march_ok && krank == 2 && fp.halo_inputs >= 1 && fp.halo_inputs <= 4 && rbig <= 8) fp.march_ok = true;
     // 3-D boxes of one halo input up to radius 2 (125 points): every live plane in LDS (neptune_apply_planes)
-    if (!fp.march_ok && rank == 3 && fp.box && fp.halo_inputs == 1 && rbig <= 2 && R[0] >= 1) fp.march_ok = true;
+    if (!fp.march_ok && krank == 3 && fp.box && fp.halo_inputs == 1 && rbig <= 2 && R[0] >= 1) fp.march_ok = true;
     if (!fp.march_ok) { fp.halo_input = -1; fp.halo_mask = 0; R[0] = R[1] = R[2] = 0; }
     return true;
   }
@@ -339,6 +364,7 @@ struct Emitter {
     std::ostringstream& o = bodies;
     o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
     o << "struct Body_" << tag << " {\n";
+    if (rank > 3) o << "  int64_t lead[3] = {0, 0, 0};   // indices along the leading (batch) dimensions, set per launch\n";
     o << "  template <class A>\n  __device__ __forceinline__ " << ctype(res.elem) << " operator()(const A& a) const {\n";
     saw_elementary = false;
     if (!emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr)) return false;
@@ -351,7 +377,7 @@ struct Emitter {
     o << "static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
     for (int k = 0; k < 4; ++k) {
       o << (k ? ", {" : "{");
-      for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (k < nin && d < rank ? fp.top_radius[k][d] : -1);
+      for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (k < nin && d < fp.rank ? fp.top_radius[k][d] : -1);
       o << "}";
     }
     o << "};\n\n";
@@ -379,7 +405,7 @@ struct Emitter {
         return false;
       }
     for (auto& t : f.arg_types) {
-      if (t.rank() < 1 || t.rank() > 3) { why = "rank " + std::to_string(t.rank()) + " argument"; return false; }
+      if (t.rank() < 1 || t.rank() > 6) { why = "rank " + std::to_string(t.rank()) + " argument"; return false; }
       if (t.elem != "f64" && t.elem != "f32") { why = "element type " + t.elem; return false; }
     }
     // every callee must be lowerable too
@@ -507,7 +533,7 @@ struct Emitter {
         // inside the reduction kernel (run_apply_reduce_sum), the temp never exists
         {
           int consumer = -1;
-          if (vi.uses == 1)
+          if (vi.uses == 1 && fp.lead == 0)
             for (size_t j = oi + 1; j < f.body.ops.size(); ++j) {
               const Op& c = *f.body.ops[j];
               if (c.name == "neptune_ir.reduce" && c.operands.at(0) == op.results[0]) { consumer = (int)j; break; }
@@ -551,6 +577,26 @@ struct Emitter {
         o << "  const nl::Val* in_" << tag << "[] = {";
         for (int k = 0; k < nin; ++k) o << (k ? ", " : "") << "&" << cname(op.operands[k]);
         o << "};\n";
+        if (fp.lead > 0) {
+          // rank 4..6: one rank-3 apply per index of the leading dimensions (lowered_runtime.hpp run_apply_batched)
+          o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply_batched<Body_" << tag << ", " << ctype(res.elem) << ", "
+            << res.bounds.rank() << ", " << nin << ", FP_" << tag << ">(sc, Body_" << tag << "{}, " << new_box(res.bounds) << ", "
+            << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ");\n";
+          ApplyInfo ai;
+          ai.function = f.name;
+          ai.tag = tag;
+          ai.rank = res.bounds.rank();
+          ai.num_inputs = fp.nin;
+          ai.march = fp.march_ok;
+          ai.box = fp.box;
+          ai.halo_input = fp.halo_inputs > 0 ? std::max(fp.halo_input, 0) : -1;
+          ai.elem = res.elem;
+          ai.halo0 = 0;
+          ai.geom_symbol = "";     // no geometry-level entry: neptune_hip_apply_geom_t is rank 1..3
+          ai.exact = fp.exact;
+          info.applies.push_back(ai);
+          continue;
+        }
         o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<Body_" << tag << ", " << ctype(res.elem) << ", "
           << res.bounds.rank() << ", " << nin << ", FP_" << tag << ">(sc, Body_" << tag << "{}, " << new_box(res.bounds) << ", "
           << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kTopRadius_" << tag << ", " << dest << ", "
@@ -604,6 +650,7 @@ struct Emitter {
         // reference's own explicit lowering (HighLevelConvertion.cpp:77-120) builds exactly this
         // apply_{linear,nonlinear} + axpy apply pair (its version is 1-D-only and ill-formed).
         const Type& st = op.types[0];
+        if (st.rank() > 3) { diag.fail(op.line, "neptune_ir.time_advance on a field of rank " + std::to_string(st.rank()) + " (rank 1..3 is lowered)"); return false; }
         ValueInfo vi;
         vi.type = st;
         vi.uses = vals[op.results[0]].uses;
@@ -740,6 +787,7 @@ struct Emitter {
       } else if (n == "neptune_ir.reduce") {
         scalar_kind[op.results[0]] = 1;   // under a slab view: this rank's partial sum
         const Type& in = op.types[0];
+        if (in.rank() > 3 && op.attrs.count("bounds")) { diag.fail(op.line, "neptune_ir.reduce {bounds} on a temp of rank " + std::to_string(in.rank()) + " (whole-buffer sums only beyond rank 3)"); return false; }
         std::string bx = "nullptr";
         if (op.attrs.count("bounds")) bx = "&" + new_box(op.attrs.at("bounds").bounds);
         auto fit = fused_reduce.find(op.operands[0]);

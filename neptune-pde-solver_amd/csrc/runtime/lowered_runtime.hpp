@@ -38,9 +38,12 @@
 namespace neptune_hip {
 namespace lowered {
 
+// fields / temps / memrefs of rank 1..6; kernels take rank 1..3, the leading dimensions of a wider apply are peeled off on
+// the host (run_apply_batched)
+constexpr int kMaxBoxRank = 6;
 struct Box {
   int rank;
-  int64_t lb[3], ub[3];
+  int64_t lb[kMaxBoxRank], ub[kMaxBoxRank];
   int64_t count() const {
     int64_t n = 1;
     for (int d = 0; d < rank; ++d) n *= (ub[d] - lb[d]);
@@ -399,6 +402,86 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const 
   return out;
 }
 
+// One neptune_ir.apply of rank R = 4..6 whose accesses have no offset along the leading R-3 dimensions (batch / component
+// dimensions; the reference's lowering is rank-generic, DataflowLowering.cpp:268-270, 301-308): for every leading index one
+// rank-3 apply on the contiguous sub-field -- inside the leading bounds the body (which sees the leading indices as members
+// `lead[]`), outside them the copy-through of input 0 (DataflowLowering.cpp:283-287).  Every input must cover the result's
+// leading extent.  No slab mode (the slab axis would be a leading dimension).
+template <class Body, class T, int R, int NIN, class FP>
+inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
+                             const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest) {
+  static_assert(R > 3 && R <= kMaxBoxRank, "run_apply_batched: rank 4..6");
+  constexpr int L = R - 3;
+  if (sc.slab()) die(sc.name(), "neptune_ir.apply of rank > 3 is not lowered in slab mode");
+  const Box bounds = Scope::zero_trip(bounds_decl);
+  auto sub_box = [](const Box& b) {
+    Box r;
+    r.rank = 3;
+    for (int d = 0; d < 3; ++d) { r.lb[d] = b.lb[L + d]; r.ub[d] = b.ub[L + d]; }
+    return r;
+  };
+  const Box out3 = sub_box(result_decl), bnd3 = sub_box(bounds);
+  for (int k = 0; k < NIN; ++k) {
+    if (in[k]->box.rank != R) die(sc.name(), "neptune_ir.apply: input rank differs from the result's");
+    for (int d = 0; d < L; ++d)
+      if (in[k]->box.lb[d] > result_decl.lb[d] || in[k]->box.ub[d] < result_decl.ub[d])
+        die(sc.name(), "neptune_ir.apply of rank > 3: an input does not cover the result's leading extent");
+  }
+  bool direct = dest != nullptr && dest->count == result_decl.count();
+  for (int k = 0; direct && k < NIN; ++k) direct = !overlaps(*dest, *in[k]);
+  Val out;
+  if (direct) {
+    out = *dest;
+    out.box = result_decl;
+  } else {
+    out = sc.alloc(result_decl, (int)sizeof(T));
+  }
+  sc.wait_pending();
+  const int64_t out_slab = out3.count();
+  int64_t lead_n = 1;
+  for (int d = 0; d < L; ++d) lead_n *= result_decl.ub[d] - result_decl.lb[d];
+  Val sub[NIN];
+  const Val* subp[NIN];
+  const void* ptrs[NIN];
+  for (int64_t flat = 0; flat < lead_n; ++flat) {
+    int64_t idx[3] = {0, 0, 0}, rem = flat;
+    for (int d = L - 1; d >= 0; --d) {
+      const int64_t n = result_decl.ub[d] - result_decl.lb[d];
+      idx[d] = result_decl.lb[d] + rem % n;
+      rem /= n;
+    }
+    bool inside = true;
+    for (int d = 0; d < L; ++d) inside = inside && idx[d] >= bounds.lb[d] && idx[d] < bounds.ub[d];
+    for (int k = 0; k < NIN; ++k) {
+      const Box& ib = in[k]->box;
+      int64_t slab = 1, off = 0;
+      for (int d = 0; d < 3; ++d) slab *= ib.ub[L + d] - ib.lb[L + d];
+      for (int d = 0; d < L; ++d) off = off * (ib.ub[d] - ib.lb[d]) + (idx[d] - ib.lb[d]);
+      sub[k] = *in[k];
+      sub[k].box = sub_box(ib);
+      sub[k].count = slab;
+      sub[k].dev = static_cast<char*>(in[k]->dev) + off * slab * (int64_t)sizeof(T);
+      subp[k] = &sub[k];
+      ptrs[k] = sub[k].dev;
+    }
+    void* outp = static_cast<char*>(out.dev) + flat * out_slab * (int64_t)sizeof(T);
+    neptune_hip_apply_geom_t g;
+    Box b3 = bnd3;
+    if (!inside) { for (int d = 0; d < 3; ++d) b3.ub[d] = b3.lb[d]; }   // zero trips: the kernel writes the copy-through only
+    fill_geom(g, out3, b3, subp, NIN);
+    int rc = inside ? geom_check_radius(&g, top_radius) : geom_validate(&g);
+    if (rc == NEPTUNE_HIP_EOOB)
+      die(sc.name(), "neptune_ir.apply reads outside an input's bounds (undefined behaviour in the reference lowering, "
+                     "DataflowLowering.cpp:380-410); refusing to run it");
+    if (rc != NEPTUNE_HIP_OK) die(sc.name(), "malformed neptune_ir.apply geometry");
+    for (int d = 0; d < L; ++d) body.lead[d] = idx[d];
+    rc = launch_apply<Body, T, 3, NIN, FP>(body, &g, ptrs, outp, sc.stream(), launch_override());
+    if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
+  }
+  if (direct) sc.mark_dirty(*dest);
+  return out;
+}
+
 // neptune_ir.store (DataflowLowering.cpp:165-220)
 inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds_decl, int dtype) {
   sc.wait_pending();   // a store may write planes the exchange is still sending
@@ -417,6 +500,7 @@ inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* boun
     }
     rc = neptune_hip_store_full(dtype, src.dev, dst.dev, src.count, sc.stream());
   } else {
+    if (src.box.rank > NEPTUNE_HIP_MAX_RANK) die(sc.name(), "neptune_ir.store {bounds} on a field of rank > 3 is not lowered");
     rc = neptune_hip_store_box(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, dst.dev, dst.box.lb, dst.box.ub,
                                bounds->lb, bounds->ub, sc.stream());
   }
@@ -441,6 +525,14 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
     clipped = sc.owned_bounds(bounds_decl ? *bounds_decl : src.box);
     bounds = &clipped;
     if (clipped.count() == 0) return 0.0;
+  }
+  if (src.box.rank > NEPTUNE_HIP_MAX_RANK) {
+    // a whole-buffer sum of a field with leading batch dimensions: the same fixed tree over the flat buffer
+    if (bounds) die(sc.name(), "neptune_ir.reduce {bounds} on a temp of rank > 3 is not lowered");
+    const int64_t flat_lb[1] = {0}, flat_ub[1] = {src.count};
+    const int rc1 = neptune_hip_reduce_sum(dtype, 1, src.dev, flat_lb, flat_ub, nullptr, nullptr, &r, sc.stream());
+    if (rc1 != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.reduce rejected");
+    return r;
   }
   const int rc = neptune_hip_reduce_sum(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, bounds ? bounds->lb : nullptr,
                                         bounds ? bounds->ub : nullptr, &r, sc.stream());
@@ -526,6 +618,9 @@ template <int RANK> struct MemRefOf;
 template <> struct MemRefOf<1> { typedef NeptuneMemRef1D type; };
 template <> struct MemRefOf<2> { typedef NeptuneMemRef2D type; };
 template <> struct MemRefOf<3> { typedef NeptuneMemRef3D type; };
+template <> struct MemRefOf<4> { typedef NeptuneMemRef4D type; };
+template <> struct MemRefOf<5> { typedef NeptuneMemRef5D type; };
+template <> struct MemRefOf<6> { typedef NeptuneMemRef6D type; };
 
 // dense row-major descriptor over `p` (results: offset 0, stride[last] = 1; reference:
 // NeptunePETScRuntime.cpp:881-892 view_x2D)

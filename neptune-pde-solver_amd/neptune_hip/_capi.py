@@ -66,7 +66,8 @@ def _memref(rank: int):
 
 
 NeptuneMemRef1D, NeptuneMemRef2D, NeptuneMemRef3D = _memref(1), _memref(2), _memref(3)
-MEMREF = {1: NeptuneMemRef1D, 2: NeptuneMemRef2D, 3: NeptuneMemRef3D}
+# rank 4..6: fields with leading batch / component dimensions (peeled off on the host, one rank-3 apply per leading index)
+MEMREF = {1: NeptuneMemRef1D, 2: NeptuneMemRef2D, 3: NeptuneMemRef3D, 4: _memref(4), 5: _memref(5), 6: _memref(6)}
 
 _vp, _i, _i64, _u64, _sz, _dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_size_t, C.c_double
 _geom_p, _cfg_p = C.POINTER(ApplyGeom), C.POINTER(LaunchCfg)
