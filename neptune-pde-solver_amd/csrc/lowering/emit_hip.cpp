@@ -787,7 +787,6 @@ struct Emitter {
       } else if (n == "neptune_ir.reduce") {
         scalar_kind[op.results[0]] = 1;   // under a slab view: this rank's partial sum
         const Type& in = op.types[0];
-        if (in.rank() > 3 && op.attrs.count("bounds")) { diag.fail(op.line, "neptune_ir.reduce {bounds} on a temp of rank " + std::to_string(in.rank()) + " (whole-buffer sums only beyond rank 3)"); return false; }
         std::string bx = "nullptr";
         if (op.attrs.count("bounds")) bx = "&" + new_box(op.attrs.at("bounds").bounds);
         auto fit = fused_reduce.find(op.operands[0]);

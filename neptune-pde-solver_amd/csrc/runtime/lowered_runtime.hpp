@@ -482,6 +482,42 @@ inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const
   return out;
 }
 
+// rank 4..6 helpers: the leading R-3 dimensions of a box as a flat range of multi-indices, and the rank-3 sub-box / offset of
+// the contiguous sub-buffer a leading multi-index names
+inline Box last3(const Box& b) {
+  Box r;
+  r.rank = 3;
+  const int L = b.rank - 3;
+  for (int d = 0; d < 3; ++d) { r.lb[d] = b.lb[L + d]; r.ub[d] = b.ub[L + d]; }
+  return r;
+}
+// cells from the start of `b`'s buffer to its sub-buffer at leading multi-index idx[0..L); -1 if idx lies outside b
+inline int64_t lead_offset_cells(const Box& b, const int64_t* idx) {
+  const int L = b.rank - 3;
+  int64_t slab = 1, off = 0;
+  for (int d = 0; d < 3; ++d) slab *= b.ub[L + d] - b.lb[L + d];
+  for (int d = 0; d < L; ++d) {
+    if (idx[d] < b.lb[d] || idx[d] >= b.ub[d]) return -1;
+    off = off * (b.ub[d] - b.lb[d]) + (idx[d] - b.lb[d]);
+  }
+  return off * slab;
+}
+template <class F>
+inline void for_each_lead(const Box& range, F&& f) {   // every leading multi-index of `range` (its first rank-3 dimensions), row-major
+  const int L = range.rank - 3;
+  int64_t n = 1;
+  for (int d = 0; d < L; ++d) n *= range.ub[d] > range.lb[d] ? range.ub[d] - range.lb[d] : 0;
+  for (int64_t flat = 0; flat < n; ++flat) {
+    int64_t idx[3] = {0, 0, 0}, rem = flat;
+    for (int d = L - 1; d >= 0; --d) {
+      const int64_t e = range.ub[d] - range.lb[d];
+      idx[d] = range.lb[d] + rem % e;
+      rem /= e;
+    }
+    f(idx);
+  }
+}
+
 // neptune_ir.store (DataflowLowering.cpp:165-220)
 inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* bounds_decl, int dtype) {
   sc.wait_pending();   // a store may write planes the exchange is still sending
@@ -500,9 +536,21 @@ inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* boun
     }
     rc = neptune_hip_store_full(dtype, src.dev, dst.dev, src.count, sc.stream());
   } else {
-    if (src.box.rank > NEPTUNE_HIP_MAX_RANK) die(sc.name(), "neptune_ir.store {bounds} on a field of rank > 3 is not lowered");
-    rc = neptune_hip_store_box(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, dst.dev, dst.box.lb, dst.box.ub,
-                               bounds->lb, bounds->ub, sc.stream());
+    if (src.box.rank > NEPTUNE_HIP_MAX_RANK) {
+      // rank 4..6: one rank-3 box copy per leading index of the stored box
+      const Box s3 = last3(src.box), d3 = last3(dst.box), b3 = last3(*bounds);
+      rc = NEPTUNE_HIP_OK;
+      for_each_lead(*bounds, [&](const int64_t* idx) {
+        const int64_t so = lead_offset_cells(src.box, idx), doff = lead_offset_cells(dst.box, idx);
+        if (so < 0 || doff < 0) { rc = NEPTUNE_HIP_EOOB; return; }
+        const int r1 = neptune_hip_store_box(dtype, 3, static_cast<char*>(src.dev) + so * src.esize, s3.lb, s3.ub,
+                                             static_cast<char*>(dst.dev) + doff * dst.esize, d3.lb, d3.ub, b3.lb, b3.ub, sc.stream());
+        if (r1 != NEPTUNE_HIP_OK && rc == NEPTUNE_HIP_OK) rc = r1;
+      });
+    } else {
+      rc = neptune_hip_store_box(dtype, src.box.rank, src.dev, src.box.lb, src.box.ub, dst.dev, dst.box.lb, dst.box.ub,
+                                 bounds->lb, bounds->ub, sc.stream());
+    }
   }
   if (rc == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.store bounds leave a buffer");
   if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.store rejected");
@@ -528,7 +576,22 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
   }
   if (src.box.rank > NEPTUNE_HIP_MAX_RANK) {
     // a whole-buffer sum of a field with leading batch dimensions: the same fixed tree over the flat buffer
-    if (bounds) die(sc.name(), "neptune_ir.reduce {bounds} on a temp of rank > 3 is not lowered");
+    if (bounds) {
+      // one rank-3 box sum per leading index of the reduced box, added up in index order
+      if (sc.slab()) die(sc.name(), "neptune_ir.reduce on a temp of rank > 3 is not lowered in slab mode");
+      const Box s3 = last3(src.box), b3 = last3(*bounds);
+      for_each_lead(*bounds, [&](const int64_t* idx) {
+        const int64_t so = lead_offset_cells(src.box, idx);
+        if (so < 0) die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");
+        double part = 0.0;
+        const int r1 = neptune_hip_reduce_sum(dtype, 3, static_cast<char*>(src.dev) + so * src.esize, s3.lb, s3.ub, b3.lb, b3.ub, &part,
+                                              sc.stream());
+        if (r1 == NEPTUNE_HIP_EOOB) die(sc.name(), "neptune_ir.reduce bounds leave the input buffer");
+        if (r1 != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.reduce rejected");
+        r += part;
+      });
+      return r;
+    }
     const int64_t flat_lb[1] = {0}, flat_ub[1] = {src.count};
     const int rc1 = neptune_hip_reduce_sum(dtype, 1, src.dev, flat_lb, flat_ub, nullptr, nullptr, &r, sc.stream());
     if (rc1 != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.reduce rejected");

@@ -62,6 +62,17 @@ module {
     %res = neptune_ir.unwrap %fo : !f -> memref<?x?x?x?x?xf32>
     func.return %res : memref<?x?x?x?x?xf32>
   }
+  func.func @boxed(%out: memref<?x?x?x?x?xf32>, %in0: memref<?x?x?x?x?xf32>, %in1: memref<?x?x?x?x?xf32>) -> f32 {
+    %fo = neptune_ir.wrap %out : memref<?x?x?x?x?xf32> -> !f
+    %f0 = neptune_ir.wrap %in0 : memref<?x?x?x?x?xf32> -> !f
+    %f1 = neptune_ir.wrap %in1 : memref<?x?x?x?x?xf32> -> !f
+    %t0 = neptune_ir.load %f0 : !f -> !t
+    %t1 = neptune_ir.load %f1 : !f -> !t
+    %y = neptune_ir.apply_nonlinear @op(%t0, %t1) : (!t, !t) -> !t
+    neptune_ir.store %y to %fo {bounds = #neptune_ir.bounds<lb = [-1, 3, 1, 0, 5], ub = [1, 5, 8, 11, 250]>} : !t to !f
+    %s = neptune_ir.reduce %t1 in #neptune_ir.bounds<lb = [0, 2, 2, 2, 3], ub = [1, 4, 9, 9, 257]> {kind = "sum"} : !t -> f32
+    func.return %s : f32
+  }
   func.func @inplace(%in0: memref<?x?x?x?x?xf32>, %in1: memref<?x?x?x?x?xf32>) -> memref<?x?x?x?x?xf32> {
     %f0 = neptune_ir.wrap %in0 : memref<?x?x?x?x?xf32> -> !f
     %f1 = neptune_ir.wrap %in1 : memref<?x?x?x?x?xf32> -> !f
@@ -86,7 +97,7 @@ def test_rank4_and_rank5_applies_are_lowered_with_their_leading_dimensions_peele
     assert "a.template get<0, -1, 0, 0>()" in src and "(int64_t)lead[0]" in src     # kernel offsets: the last three dimensions
     assert "neptune_hip::Footprint<0, 1, 1, 1, false, true>" in src
     src5, rep5 = lowering.to_hip(rank5_text())
-    assert rep5["lowered"] == ["op", "entry", "inplace"]
+    assert rep5["lowered"] == ["op", "entry", "boxed", "inplace"]
     assert "lead[0]" in src5 and "lead[1]" in src5 and "a.template idx<2>()" in src5
     # an offset along a leading dimension is refused with a diagnostic (the function is not lowered)
     bad = FIXTURE.read_text().replace("%a[0, -1, 0, 0]", "%a[-1, 0, 0, 0]")
@@ -157,3 +168,13 @@ def test_rank5_apply_two_inputs_in_place(env):
     a_host = a.copy()
     mod.call("inplace", a_host, c)
     assert bits_equal(a_host, want)
+    # store {bounds} and reduce {bounds} beyond rank 3: one rank-3 box copy / box sum per leading index
+    want_b = np.full(shape, 9.0, dtype=np.float32)
+    want_s = m.call("boxed", want_b, a, c)
+    d_out = torch.full(shape, 9.0, dtype=torch.float32, device="cuda")
+    got_s = mod.call("boxed", d_out, torch.from_numpy(a).cuda(), torch.from_numpy(c).cuda())
+    assert bits_equal(d_out.cpu().numpy(), want_b)
+    assert bits_equal(want_b[0, 0], np.full(shape[2:], 9.0, dtype=np.float32)) and not bits_equal(want_b[1, 2], want_b[0, 0])
+    box = c[1:2, 0:2, 2:9, 2:9, 3:257].astype(np.float64)
+    tol = 2 * (box.size - 1) * np.finfo(np.float32).eps * np.abs(box).sum()
+    assert abs(float(got_s) - float(box.sum())) <= tol and abs(float(want_s) - float(box.sum())) <= tol
