@@ -41,8 +41,16 @@ module {{
 '''
 
 
+def compile_shared(text):
+    """one cache for all ranks (and for both world sizes of the test): rank 0 compiles, the others load the object"""
+    if dist.get_rank() == 0:
+        lowering.compile_module(text)
+    dist.barrier()
+    return lowering.compile_module(text)
+
+
 def run_case(rank, world, text, symbol, shape, steps, check_oracle=True):
-    mod = lowering.compile_module(text)
+    mod = compile_shared(text)
     u = helpers.hash_field(shape, np.float64, seed=17)
     # single process, whole field
     a, b = torch.from_numpy(u).cuda(), torch.zeros(shape, dtype=torch.float64, device="cuda")
@@ -76,7 +84,7 @@ def run_geom_entry_case(rank, world, text, function, shape, radius, nin, steps):
     """the module's apply through ShardedApply (exchange overlapped with the interior launch, then the edge
     launches) via its geometry-level entry, against the single-process call of the exported opdef"""
     from neptune_hip import fields
-    mod = lowering.compile_module(text)
+    mod = compile_shared(text)
     entry = mod.geom_entry(function)
     assert entry.halo0 == radius and entry.num_inputs == nin
     us = [helpers.hash_field(shape, np.float64, seed=29 + k) for k in range(nin)]
@@ -115,7 +123,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     torch.cuda.set_device(0)
-    os.environ["NEPTUNE_CACHE_DIR"] = os.environ["SLAB_CACHE_DIR"] + f"/r{rank}"
+    os.environ["NEPTUNE_CACHE_DIR"] = os.environ["SLAB_CACHE_DIR"]
     ok = {}
     shape = (24, 12, 256)
     text = make_stencil_mlir.stencil_module("3d7", list(shape), time_step=0.125)
@@ -144,7 +152,7 @@ def main():
     ok["geom_entry_2d_radius4"] = run_geom_entry_case(rank, world, r4, "resid", (40, 256), 4, 1, 2)
     # reduce: every rank sums its owned planes, the partial sums are added
     n0, n1 = 37, 256
-    red = lowering.compile_module(SUMSQ.format(n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1))
+    red = compile_shared(SUMSQ.format(n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1))
     u = helpers.hash_field((n0, n1), np.float64, seed=23)
     whole = red.call("sumsq", torch.from_numpy(u).cuda())
     sl = slab_mod.decompose(([0, 0], [n0, n1]), 1, rank, world)

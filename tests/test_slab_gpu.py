@@ -31,11 +31,17 @@ def test_sharded_apply_on_one_gpu(built_libs, world, kind, shape, steps):
     assert f"SLAB_GPU_OK world={world}" in p.stdout
 
 
+@pytest.fixture(scope="module")
+def shared_cache(tmp_path_factory):
+    return tmp_path_factory.mktemp("neptune_cache_slab_modules")
+
+
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_lowered_module_on_one_gpu(built_libs, tmp_path, world):
+def test_sharded_lowered_module_on_one_gpu(built_libs, shared_cache, world):
     """lowered modules (fixtures, fused and two-stage time steps, a reduce) through ShardedModule: compiled
-    once for the global boxes, called on local slab buffers under neptune_hip_set_slab()"""
-    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_CACHE_DIR=str(tmp_path))
+    once for the global boxes (rank 0 compiles into a cache both world sizes share, the other ranks load the
+    objects), called on local slab buffers under neptune_hip_set_slab()"""
+    env = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SLAB_CACHE_DIR=str(shared_cache))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(HERE / "slab_module_worker.py")]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
