@@ -257,8 +257,10 @@ constexpr bool plane_only() {
 template <class T, class FP, int RANK>
 constexpr bool tile2_only() {
   constexpr int VK = 16 / (int)sizeof(T), NH = popcount_u(FP::HALO_MASK), rbig = FP::R0 > FP::R2 ? FP::R0 : FP::R2;
+  // ... and what they hold worse than the LDS tile does (8192^2, profiles/r02_plane.txt section 7): stars from radius 3 on (radius 3
+  // ragged 4.76 TB/s against 4.07 on the march form, radius 4 level), 5x5 boxes (4.04 against 3.37)
   return tile2_capable<T, FP, RANK>() &&
-         ((!FP::BOX && (FP::R0 > 4 || FP::R2 > 4 || FP::R2 > 2 * VK)) || (FP::BOX && rbig > 2) || (NH > 1 && (rbig > 2 || (FP::BOX && rbig > 1))));
+         ((!FP::BOX && rbig > 2) || FP::R2 > 2 * VK || (FP::BOX && rbig > 1) || (NH > 1 && (rbig > 2 || (FP::BOX && rbig > 1))));
 }
 template <class T, class FP, int RANK, int RJ, int WJ, int WK, bool DPP, bool NT, int PF, bool NTL, bool LDSJ, bool JK, bool JHL, int KD, bool PLN>
 struct TileFor {
