@@ -17,20 +17,30 @@ BINDIR   := $(PKG)/bin
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function \
             -Wno-unused-but-set-variable -Wno-unused-variable
 KERNEL_HDRS := $(wildcard $(CSRC)/kernels/*.hpp) $(wildcard $(CSRC)/runtime/*.hpp) include/neptune_hip.h
+# names the kernel sources a code object was compiled from: part of every launch-wisdom key (include/neptune_hip.h)
+BUILD_ID := $(shell cat $(sort $(KERNEL_HDRS)) | sha256sum | cut -c1-16)
+HIPFLAGS += -DNEPTUNE_HIP_BUILD_ID=\"$(BUILD_ID)\"
 
 .PHONY: all rt lowering oracle clean resources
 all: rt lowering oracle
 
-# two translation units: the kernels + runtime (minutes: every tile x every built-in body) and the host-only slab /
-# RCCL code (seconds)
+# translation units: the runtime proper, one per built-in body (minutes each: every tile of the library -- built side
+# by side under make -j), and the host-only slab / wisdom code (seconds each)
 rt: $(LIBDIR)/libneptune_hip.so
 build/obj/neptune_hip_rt.o: $(CSRC)/runtime/neptune_hip_rt.hip $(KERNEL_HDRS)
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+build/obj/rt_body_%.o: $(CSRC)/runtime/rt_body_%.hip $(KERNEL_HDRS)
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 build/obj/slab_rccl.o: $(CSRC)/runtime/slab_rccl.hip $(CSRC)/runtime/slab_rccl.hpp $(CSRC)/kernels/apply_launch.hpp include/neptune_hip.h
 	@mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(LIBDIR)/libneptune_hip.so: build/obj/neptune_hip_rt.o build/obj/slab_rccl.o
+build/obj/wisdom.o: $(CSRC)/runtime/wisdom.hip include/neptune_hip.h
+	@mkdir -p build/obj
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+RT_BODIES := lap2d5 lap3d7 lap3d27 lap1d3
+$(LIBDIR)/libneptune_hip.so: build/obj/neptune_hip_rt.o $(RT_BODIES:%=build/obj/rt_body_%.o) build/obj/slab_rccl.o build/obj/wisdom.o
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -shared $^ -ldl -o $@
 

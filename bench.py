@@ -12,8 +12,14 @@ every step reads what the previous one wrote.  Inputs are resident in HBM before
 region; nothing crosses PCIe inside it.
 
 N > 1: the field is cut into dim-0 slabs (strong scaling: the global problem stays 1024^3),
-each step exchanges one halo plane per neighbour over RCCL/xGMI on a second stream, overlapped
-with the interior update (neptune_hip/slab.py).
+each step exchanges one halo plane per neighbour over xGMI on a second stream, overlapped
+with the interior update (include/neptune_hip.h section 8; neptune_hip/slab.py).  Every halo
+transport is CHECKED at start-up (ghost planes poisoned, exchanged, compared), the ones that
+pass are timed for a few steps and the fastest is used; a start-up watchdog ends a run whose
+communicator set-up never returns, naming the stage.
+
+After the timed region the run verifies itself (sampled planes of one more step, bit for bit
+against the CPU oracle) and, on one GPU, times the other single-GPU BASELINE configurations.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how every field is derived.
 """
@@ -22,11 +28,13 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO / "neptune-pde-solver_amd"))
+sys.path.insert(0, str(REPO / "tools"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 
@@ -38,7 +46,12 @@ WORKLOADS = {
     "2d5_1024": ("lap2d5_f64", (1024, 1024), 8, 5),
     "3d27_512": ("lap3d27_f32", (512, 512, 512), 4, 27),
 }
+KIND = {"lap3d7_f64": "3d7", "lap2d5_f64": "2d5", "lap3d27_f32": "3d27"}
+FIXTURE = {"lap3d7_f64": "apply-3d-7pt.mlir", "lap2d5_f64": "apply-2d-5pt.mlir", "lap3d27_f32": "apply-3d-27pt.mlir"}
 ORACLE_FN = {"lap3d7_f64": "lap3d7_f64", "lap2d5_f64": "lap2d5_f64", "lap3d27_f32": "lap3d27_f32"}
+# the other single-GPU configurations of BASELINE.json, timed after the headline on one GPU (config.configs)
+EXTRA_CONFIGS = ["3d7_512", "2d5_8192", "3d27_512"]
+SEED = 2024
 
 
 def parse_args():
@@ -54,17 +67,22 @@ def parse_args():
                     help="skip the plan-time tuning (untimed, before warm-up) and use the library's default tile")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos before the interior (debug)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="diagnostic: run the multi-rank code path with every rank on cuda:0 and gloo as transport "
-                         "(halos staged through host memory); checks the control flow, not the speed")
+                    help="diagnostic: run the multi-rank code path with every rank on cuda:0 and gloo as process group; the "
+                         "halo planes move over the peer transport (which two processes on one device can use) or, with "
+                         "--halo-transport torch, staged through host memory; checks the control flow, not the speed")
     ap.add_argument("--emulate-rank", default="",
                     help="diagnostic, single process: 'R/W' runs the compute launches rank R of W would issue "
-                         "(interior + edge regions of its slab, no exchange) to tune slab-sized kernels on one GPU")
+                         "(interior + edge regions of its slab) with a loop-back exchange, to tune slab-sized kernels on one GPU")
     ap.add_argument("--allow-host-staging", action="store_true",
-                    help="N>1: if no RCCL transport passes its start-up check, stage the halo planes through host memory over a "
+                    help="N>1: if no device transport passes its start-up check, stage the halo planes through host memory over a "
                          "gloo group instead of failing (a PCIe number, not an xGMI one; reported in config.halo_transport)")
-    ap.add_argument("--halo-transport", default="auto", choices=["auto", "c-abi", "torch"],
-                    help="N>1: auto = the C-ABI exchange (libneptune_hip.so issues ncclSend/ncclRecv itself), falling back to "
-                         "torch.distributed point-to-point ops if its start-up check fails; c-abi / torch force one")
+    ap.add_argument("--halo-transport", default="auto", choices=["auto", "c-abi", "peer", "torch"],
+                    help="N>1: auto = check the C-ABI RCCL exchange (libneptune_hip.so issues ncclSend/ncclRecv itself), the C-ABI "
+                         "peer-copy exchange (hipIpc mappings + SDMA pushes, no CU moves data) and torch.distributed "
+                         "point-to-point ops, time the ones that pass and keep the fastest; c-abi / peer / torch force one")
+    ap.add_argument("--startup-timeout", type=float, default=120.0,
+                    help="seconds any single start-up stage (process group, communicator, first exchange) may take before the "
+                         "watchdog prints the stage and exits with code 4")
     ap.add_argument("--fixed-input", action="store_true",
                     help="diagnostic: every step reads field 0 and writes field 1 (no ping-pong)")
     ap.add_argument("--builtin", action="store_true",
@@ -76,10 +94,60 @@ def parse_args():
                     help="build the lowered module with every march tile of the library (NEPTUNE_HIP_FULL_VARIANTS=1: "
                          "a longer hipcc run) so that the plan-time tuning can choose among all of them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="N=1, default workload: skip the other single-GPU BASELINE configurations (config.configs)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the self-check against the oracle after the timed region")
+    ap.add_argument("--compile-only", action="store_true",
+                    help="lower + hipcc the module(s) this command line needs into the cache and exit without touching the GPU "
+                         "(run before profiling: a profiled run must be a pure cache hit)")
     ap.add_argument("--cpu-sample-planes", type=int, default=0, help="dim-0 extent of the CPU sample (0 = auto)")
     ap.add_argument("--hbm-traffic-bytes", type=float, default=None,
                     help="per-launch HBM bytes from a separate rocprofv3 --pmc pass (reported as roofline.traffic)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """A run whose communicator set-up blocks for ever burns the driver's whole time limit and leaves no diagnosis.
+    Every start-up stage announces itself here with a time limit; if it has not finished by then the watchdog thread
+    prints which stage of which rank is stuck and ends the process with exit code 4 (exit -- never re-exec: this
+    process has initialised the GPU)."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.lock = threading.Lock()
+        self.name, self.deadline, self.t0 = None, None, None
+        self.history = []
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def stage(self, name, limit):
+        with self.lock:
+            self._close()
+            self.name, self.t0, self.deadline = name, time.monotonic(), time.monotonic() + limit
+
+    def done(self):
+        with self.lock:
+            self._close()
+
+    def _close(self):
+        if self.name is not None:
+            self.history.append((self.name, round(time.monotonic() - self.t0, 2)))
+        self.name = self.deadline = None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                name, deadline, t0 = self.name, self.deadline, self.t0
+            if name is not None and time.monotonic() > deadline:
+                print(f"[bench] rank {self.rank}: WATCHDOG: stage '{name}' has not returned after {time.monotonic() - t0:.0f} s; "
+                      f"stages completed before it: {self.history}.  Exiting with code 4.", file=sys.stderr, flush=True)
+                os._exit(4)
+
+
+def fixture_text(body_name, shape):
+    import make_stencil_mlir
+    return make_stencil_mlir.stencil_module(KIND[body_name], list(shape))
 
 
 def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
@@ -90,6 +158,11 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
     lib_path = REPO / "oracle" / "_build" / "liboracle.so"
     if not lib_path.exists():
         return None
+    # the fused leg runs one OpenMP thread per CPU this process may use: say so explicitly instead of leaving it to the
+    # OpenMP runtime's default (which read 128 of 256 usable CPUs on the round-2 boxes); set before the library loads
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(usable)
+    os.environ.setdefault("OMP_PROC_BIND", "false")
     lib = C.CDLL(str(lib_path))
     nd = len(shape)
     ct = C.c_double if elem_bytes == 8 else C.c_float
@@ -108,7 +181,7 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
     fill.restype = None
     u = np.empty(sshape, dt)
     out = np.zeros(sshape, dt)   # touch the destination like the reference driver does (out[i] = 0)
-    fill(u.ctypes.data_as(C.POINTER(ct)), count, 0, 2024)
+    fill(u.ctypes.data_as(C.POINTER(ct)), count, 0, SEED)
     lb = (C.c_int64 * nd)(*([1] * nd))
     ub = (C.c_int64 * nd)(*[n - 1 for n in sshape])
     updates = 1
@@ -136,29 +209,47 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
         "value": res["entry"][0], "unit": "cell-updates/s", "cores": 1, "kind": "port",
         "sample": f"{dims} slab of the workload (same plane size), faithful restatement of the reference "
                   f"lowering: malloc + copy-through + scalar loop nest + store copy, best of 3 runs, {res['entry'][1]:.2f} s each",
-        # the fused leg runs on OpenMP's default team = the CPUs this process may use (its affinity mask / cgroup
-        # share), which on a shared GPU node is less than the machine's core count: both are reported
         "fused_all_cores": {"value": res["fused"][0], "cores": threads, "seconds": res["fused"][1],
-                            "cores_note": "OpenMP default team: the CPUs in this process's affinity mask"},
+                            "cores_note": f"OMP_NUM_THREADS set to the {usable} CPUs in this process's affinity mask; the OpenMP "
+                                          f"runtime reports {threads} threads"},
         "host_cores": os.cpu_count(),
-        "host_cores_usable": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        "host_cores_usable": usable,
     }
 
 
 def main():
     args = parse_args()
+    body_name, gshape, esize, points = WORKLOADS[args.workload]
+    args.lowered = not args.builtin
+    if args.full_variants:
+        os.environ["NEPTUNE_HIP_FULL_VARIANTS"] = "1"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    extra = (world == 1 and args.workload == "3d7_1024" and not args.emulate_rank and not args.no_extra_configs
+             and args.kernel == "auto" and args.variant < 0 and args.chunk == 0 and args.lowered)
+
+    if args.compile_only:
+        from neptune_hip import lowering as nh_lowering
+        if args.lowered:
+            nh_lowering.compile_module(fixture_text(body_name, gshape), load=False)
+        if extra:
+            for name in EXTRA_CONFIGS:
+                nh_lowering.compile_module(fixture_text(WORKLOADS[name][0], WORKLOADS[name][1]), load=False)
+        return
+
     # stdout carries exactly ONE JSON line.  RCCL prints a version banner and gloo its connection notes to file
     # descriptor 1 from C code: keep a private handle on the real stdout for the JSON line and point fd 1 at stderr
     # for everything else.
     json_out = os.fdopen(os.dup(1), "w")
     sys.stdout.flush()
     os.dup2(2, 1)
+    dog = Watchdog(rank)
+    dog.stage("import torch", 600)
     import torch
     import torch.distributed as dist
+    dog.done()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
@@ -175,30 +266,52 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dog.stage("torch.distributed.init_process_group", args.startup_timeout)
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dog.done()
     coll_dev = "cpu" if args.rehearse_on_one_gpu else "cuda"   # device of the few control tensors
 
-    body_name, gshape, esize, points = WORKLOADS[args.workload]
-    body = nh_apply.BODY_BY_NAME[body_name]
-    builtin_body = body
-    args.lowered = not args.builtin
+    def ranks_agree(ok: bool) -> bool:
+        if world == 1:
+            return ok
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag.item()))
+
+    def max_over_ranks(*vals):
+        if world == 1:
+            return [float(v) for v in vals]
+        t = torch.tensor(list(vals), dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if world > 1:   # the first collective builds torch's own communicator: a stage of its own
+        dog.stage("first torch.distributed collective (all_reduce)", args.startup_timeout)
+        ranks_agree(True)
+        torch.cuda.synchronize()
+        dog.done()
+
+    builtin_body = nh_apply.BODY_BY_NAME[body_name]
+    body = builtin_body
     if args.lowered:
-        if args.full_variants:
-            os.environ["NEPTUNE_HIP_FULL_VARIANTS"] = "1"
-        sys.path.insert(0, str(REPO / "tools"))
-        import make_stencil_mlir
         from neptune_hip import lowering as nh_lowering
-        kind = {"lap3d7_f64": "3d7", "lap2d5_f64": "2d5", "lap3d27_f32": "3d27"}[body_name]
-        text = make_stencil_mlir.stencil_module(kind, list(gshape))
+        import make_stencil_mlir
+        text = fixture_text(body_name, gshape)
+        dog.stage("lowering + hipcc of the module", 900)
         if world > 1:                      # one rank fills the module cache, the others load from it
             if rank == 0:
-                nh_lowering.compile_module(text)
+                nh_lowering.compile_module(text, load=False)
             dist.barrier()
         module = nh_lowering.compile_module(text)
-        body = module.geom_entry(make_stencil_mlir.KINDS[kind][2])     # the fixture's opdef (@lap3d, ...)
+        dog.done()
+        body = module.geom_entry(make_stencil_mlir.KINDS[KIND[body_name]][2])     # the fixture's opdef (@lap3d, ...)
     dtype = nh_apply.BODY_DTYPE[builtin_body]
     rank_nd = len(gshape)
     gbox = ([0] * rank_nd, list(gshape))
@@ -219,10 +332,15 @@ def main():
     for n in gshape[1:]:
         plane_cells *= n
     bufs = [fields.DeviceField(sl.local_lb, sl.local_ub, dtype) for _ in range(2)]
-    # global deterministic field: value depends on the GLOBAL linear index, so every rank count
-    # works on the same data
-    bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
-    bufs[1].tensor.zero_()
+    index_offset = (sl.local_lb[0] - gbox[0][0]) * plane_cells
+
+    def refill():
+        # global deterministic field: value depends on the GLOBAL linear index, so every rank count works on the same data
+        bufs[0].fill_hash(SEED, index_offset=index_offset)
+        bufs[1].tensor.zero_()
+        torch.cuda.synchronize()
+
+    refill()
     # Plan-time tuning, untimed and before any warm-up or timed step: the library times its tiles on
     # exactly this rank's dominant launch (the interior region of its slab) and keeps the fastest.
     # Every tile computes the same bits; explicit --variant/--chunk/--kernel switch it off.
@@ -236,22 +354,19 @@ def main():
             cfg = nh_apply.make_cfg(kernel, args.variant, args.chunk)
         bufs[1].tensor.zero_()
         del probe
-    # Halo transport.  RCCL builds its point-to-point channels on first use (seconds): do that here, outside every timed
-    # or counted step, and CHECK the result -- the ghost planes of the freshly filled field already hold the right global
-    # values, so: keep a copy, poison them, exchange, compare.  Order of preference:
-    #   1. the C-ABI path (include/neptune_hip.h section 8): libneptune_hip.so issues the grouped ncclSend/ncclRecv on
-    #      its own communication stream; a sharded step is ONE call into the library;
-    #   2. torch.distributed point-to-point ops on the default (nccl = RCCL) group;
-    #   3. only with --allow-host-staging: planes staged through host memory over a gloo group.
-    # A transport that fails or delivers wrong planes on ANY rank is dropped on ALL ranks (agreed through an all-reduce);
-    # if none is left the run ends with a non-zero exit code instead of printing a number.
-    halo_group, rccl_comm, transport = None, None, ("none" if world == 1 else None)
 
-    def ranks_agree(ok: bool) -> bool:
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=coll_dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        return bool(int(flag.item()))
-
+    # ---- halo transport ------------------------------------------------------------------------------------------
+    # Every candidate is CHECKED before it is trusted -- the ghost planes of the freshly filled field already hold the
+    # right global values, so: keep a copy, poison them, exchange, compare -- and a transport that fails or delivers
+    # wrong planes on ANY rank is dropped on ALL ranks (agreed through an all-reduce).  The ones that pass run a few
+    # untimed-for-the-result steps each and the fastest is kept (config.halo_transports records every verdict):
+    #   rccl-c  the C-ABI path (include/neptune_hip.h section 8): libneptune_hip.so issues the grouped ncclSend/ncclRecv
+    #           on its own priority stream; a sharded step is ONE call into the library
+    #   peer-c  the same C plan on the peer-copy transport: each rank pushes its edge planes into its neighbour's ghost
+    #           planes through an IPC mapping (hipMemcpyAsync: SDMA over xGMI, no CU moves data), handshake kernels
+    #   torch   torch.distributed point-to-point ops on the default (nccl = RCCL) group
+    # Only with --allow-host-staging: planes staged through host memory over a gloo group.  If none is left the run
+    # ends with a non-zero exit code instead of printing a number.
     def exchange_is_correct(do_exchange, what) -> bool:
         t = bufs[0].tensor
         lo, hi = sl.owned_planes()
@@ -269,60 +384,127 @@ def main():
         except Exception as e:                      # noqa: BLE001 - whatever the transport raises means "unusable"
             ok = False
             print(f"[bench] rank {rank}: {what} failed ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
-        bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
-        torch.cuda.synchronize()
+        refill()
         return ok
 
-    if world > 1 and args.rehearse_on_one_gpu:
-        transport = "gloo-host-staged (rehearsal)"
-    elif world > 1 and emu is None:
-        if args.halo_transport in ("auto", "c-abi"):
-            ok = True
-            try:
-                rccl_comm = slab_mod.RcclComm.from_process_group()
-            except Exception as e:                  # noqa: BLE001
-                ok = False
-                print(f"[bench] rank {rank}: C-ABI communicator: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-            if ranks_agree(ok):
-                ok = exchange_is_correct(lambda t: rccl_comm.exchange(sl, t), "C-ABI halo exchange")
-            if ranks_agree(ok):
-                transport = "rccl, C ABI (neptune_hip_slab_apply: ncclSend/ncclRecv issued by libneptune_hip.so)"
-            else:
-                rccl_comm = None
-        if transport is None and args.halo_transport in ("auto", "torch"):
-            def torch_p2p(t):
-                for w in slab_mod.exchange_halos(sl, t):
-                    w.wait()
-            if ranks_agree(exchange_is_correct(torch_p2p, "torch.distributed point-to-point exchange")):
-                transport = "rccl, torch.distributed point-to-point"
-        if transport is None:
-            if not args.allow_host_staging:
-                if rank == 0:
-                    print("[bench] no RCCL halo transport passed its start-up check (see the messages above); refusing to "
-                          "fall back to host staging without --allow-host-staging", file=sys.stderr, flush=True)
-                dist.barrier()
-                dist.destroy_process_group()
-                sys.exit(3)
-            halo_group, transport = dist.new_group(backend="gloo"), "gloo-host-staged (no RCCL transport passed its check)"
-    elif emu is not None and (sl.r_lo or sl.r_hi):
-        # single-process emulation of rank R of W: the same C-ABI step with the rank itself as both neighbours (an RCCL
-        # communicator of one rank, loop-back send/recv): every stream operation and launch of the real step, with the
-        # halo planes copied on the device instead of crossing xGMI
-        rccl_comm = slab_mod.RcclComm(0, 1)
-        transport = "rccl, C ABI, loop-back to the same rank (emulation)"
-    op = slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=halo_group, comm=rccl_comm,
-                               peers=(0, 0) if emu is not None else None)
-    sharded = op
-    stream_ptr = fields.current_stream_ptr()
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    def make_op(comm=None, group=None, peers=None):
+        return slab_mod.ShardedApply(sl, body, gbounds, cfg=cfg, overlap=not args.no_overlap, group=group, comm=comm, peers=peers)
 
-    def step(s):
+    def step_with(op, s):
         if args.fixed_input:
             op(bufs[0], bufs[1])
         else:
             op(bufs[s % 2], bufs[(s + 1) % 2])
+
+    def time_steps(op, n, warm):
+        """ms per step of `n` steps after `warm` untimed ones, barrier to barrier, max over ranks"""
+        refill()
+        for s in range(warm):
+            step_with(op, s)
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(warm, warm + n):
+            step_with(op, s)
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks((time.perf_counter() - t0) * 1e3 / n)[0]
+
+    DESCR = {
+        "rccl-c": "rccl, C ABI (neptune_hip_slab_apply: ncclSend/ncclRecv issued by libneptune_hip.so)",
+        "peer-c": "peer copies, C ABI (neptune_hip_slab_apply: hipMemcpyAsync into the neighbour's IPC-mapped ghost planes, "
+                  "handshake kernels; no CU moves data)",
+        "torch": "rccl, torch.distributed point-to-point",
+    }
+    halo_group, comms, ops, verdicts, transport, chosen = None, {}, {}, {}, ("none" if world == 1 else None), None
+    if world > 1 and emu is None:
+        wanted = {"auto": ["rccl-c", "peer-c", "torch"], "c-abi": ["rccl-c"], "peer": ["peer-c"], "torch": ["torch"]}[args.halo_transport]
+        if args.rehearse_on_one_gpu:       # two processes cannot share a device under RCCL; the peer transport can
+            wanted = [w for w in wanted if w == "peer-c"]
+        for name in wanted:
+            ok, comm = True, None
+            if name in ("rccl-c", "peer-c"):
+                dog.stage(f"communicator for the '{name}' transport", args.startup_timeout)
+                try:
+                    comm = slab_mod.SlabComm.from_process_group(transport="rccl" if name == "rccl-c" else "peer")
+                except Exception as e:                  # noqa: BLE001
+                    ok = False
+                    print(f"[bench] rank {rank}: {name} communicator: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                ok = ranks_agree(ok)
+                if ok:
+                    dog.stage(f"first checked halo exchange on the '{name}' transport", args.startup_timeout)
+                    ok = ranks_agree(exchange_is_correct(lambda t, c=comm: c.exchange(sl, t), f"{name} halo exchange"))
+            else:
+                dog.stage("first checked halo exchange on the 'torch' transport", args.startup_timeout)
+
+                def torch_p2p(t):
+                    for w in slab_mod.exchange_halos(sl, t):
+                        w.wait()
+                ok = ranks_agree(exchange_is_correct(torch_p2p, "torch.distributed point-to-point exchange"))
+            verdicts[name] = {"ok": ok}
+            if ok:
+                dog.stage(f"timing a few steps on the '{name}' transport", args.startup_timeout)
+                op = make_op(comm=comm)
+                try:
+                    verdicts[name]["ms_per_step"] = time_steps(op, 10, 3)
+                    if comm is not None:
+                        comm.status()
+                    comms[name], ops[name] = comm, op
+                except Exception as e:                  # noqa: BLE001
+                    print(f"[bench] rank {rank}: {name} steps: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                    verdicts[name] = {"ok": False, "error": "steps failed"}
+                    ok = False
+                if not ranks_agree(ok):
+                    verdicts[name]["ok"] = False
+                    comms.pop(name, None)
+                    ops.pop(name, None)
+            elif comm is not None:
+                comm.close()
+            dog.done()
+        usable = [n for n in wanted if n in ops]
+        if usable:
+            chosen = min(usable, key=lambda n: verdicts[n]["ms_per_step"])
+            if world > 1:    # every rank holds the same max-over-ranks times, but agree explicitly
+                pick = torch.tensor([wanted.index(chosen)], dtype=torch.int32, device=coll_dev)
+                dist.broadcast(pick, 0)
+                chosen = wanted[int(pick.item())]
+            transport = DESCR[chosen]
+            for n in usable:
+                if n != chosen:
+                    ops.pop(n)
+                    torch.cuda.synchronize()
+                    if comms.get(n) is not None:
+                        comms.pop(n).close()
+        elif args.rehearse_on_one_gpu and args.halo_transport == "torch":
+            transport = "gloo-host-staged (rehearsal)"
+        elif not args.allow_host_staging:
+            if rank == 0:
+                print("[bench] no device halo transport passed its start-up check (see the messages above); refusing to "
+                      "fall back to host staging without --allow-host-staging", file=sys.stderr, flush=True)
+            dist.barrier()
+            dist.destroy_process_group()
+            sys.exit(3)
+        else:
+            halo_group, transport = dist.new_group(backend="gloo"), "gloo-host-staged (no device transport passed its check)"
+    elif emu is not None and (sl.r_lo or sl.r_hi):
+        # single-process emulation of rank R of W: the same C-ABI step with the rank itself as both neighbours (a
+        # communicator of one rank, loop-back): every stream operation and launch of the real step, with the halo planes
+        # copied on the device instead of crossing xGMI
+        which = "peer" if args.halo_transport == "peer" else "rccl"
+        comms["emu"] = slab_mod.SlabComm(0, 1, transport=which)
+        transport = f"{which}, C ABI, loop-back to the same rank (emulation)"
+    if chosen is not None:
+        op = ops[chosen]
+    elif emu is not None:
+        op = make_op(comm=comms.get("emu"), peers=(0, 0))
+    else:
+        op = make_op(group=halo_group)
+    sharded = op
+    the_comm = comms.get(chosen) if chosen is not None else comms.get("emu")
+    stream_ptr = fields.current_stream_ptr()
+
+    def step(s):
+        step_with(op, s)
 
     # Clock ramp: the chip leaves its idle clocks only after some tens of milliseconds of load, which
     # is longer than the whole run of the small workloads (512^3: 0.2-0.4 ms per step).  Spend ~1 s (0.3 s was not
@@ -333,12 +515,13 @@ def main():
     # restored every 10 ramp steps as well: launches on overflowed inf/NaN data draw less power and run ~7 %
     # faster than on real data (kernel trace of the 27-point workload: 181 us against 197 us), which would make
     # the ramp unrepresentative and skew a profiler's per-kernel average.
+    dog.stage("clock ramp", 300)
     t_ramp = time.perf_counter()
     n_ramp = 0
     while True:
         for s in range(10):
             step(s)
-        bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
+        bufs[0].fill_hash(SEED, index_offset=index_offset)
         torch.cuda.synchronize()
         n_ramp += 10
         go = time.perf_counter() - t_ramp < 1.0 and n_ramp < 6000
@@ -348,11 +531,10 @@ def main():
             go = bool(int(flag.item()))
         if not go:
             break
-    bufs[0].fill_hash(2024, index_offset=(sl.local_lb[0] - gbox[0][0]) * plane_cells)
-    bufs[1].tensor.zero_()
-    torch.cuda.synchronize()
+    refill()
     barrier()
 
+    dog.stage("warm-up and timed steps", 600)
     for s in range(args.warmup):
         step(s)
     torch.cuda.synchronize()
@@ -371,11 +553,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     ev_ms = lib.neptune_hip_event_elapsed_ms(ev0, ev1)
-
-    if world > 1:
-        t = torch.tensor([elapsed, ev_ms], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, ev_ms = float(t[0]), float(t[1])
+    dog.done()
+    elapsed, ev_ms = max_over_ranks(elapsed, ev_ms)
+    if the_comm is not None:
+        the_comm.status()       # a device-side wait of the peer transport that timed out means stale ghost planes: not a result
 
     # guard against a silently dead run: the result must be finite and must have changed
     probe = bufs[(args.warmup + args.steps) % 2].tensor
@@ -383,6 +564,61 @@ def main():
     mid = probe[(lo + hi) // 2]
     assert bool(torch.isfinite(mid).all()), "non-finite values in the result"
     assert float(mid.abs().max()) > 0.0, "result is identically zero"
+
+    # ---- where a sharded step's time goes (untimed-for-the-result extra steps; C-ABI transports only) -----------------
+    breakdown = None
+    if (world > 1 or emu is not None) and hasattr(op, "rccl") and op.rccl is not None:
+        dog.stage("per-step timing breakdown", 300)
+        op.timing(True)
+        for s in range(20):
+            step(s)
+        torch.cuda.synchronize()
+        mine = op.read_timing()
+        op.timing(False)
+        if mine is not None:
+            keys = ["exchange_ms", "interior_ms", "edge_wait_ms", "edges_ms", "step_ms"]
+            worst = max_over_ranks(*[mine[k] for k in keys])
+            breakdown = {"rank0": {k: round(mine[k], 4) for k in keys} if rank == 0 else None,
+                         "max_over_ranks": {k: round(v, 4) for k, v in zip(keys, worst)},
+                         "steps_averaged": mine["steps"],
+                         "note": "HIP events inside neptune_hip_slab_apply: exchange on the communication stream (input ready -> "
+                                 "ghost planes landed), interior and edge launches on the compute stream; edge_wait = how long "
+                                 "after the interior's end the exchange ended (0 = hidden behind it)"}
+        barrier()
+        dog.done()
+
+    # ---- the configuration the dominant launch really used -----------------------------------------------------------
+    launched = _capi.LaunchCfg()
+    dom_region = sharded.interior if ((world > 1 or emu is not None) and sharded.interior is not None) else sharded._own_region()
+    nh_apply.apply_builtin(body, [bufs[0]], bufs[1], sharded.bounds, region=dom_region, cfg=cfg)
+    torch.cuda.synchronize()
+    have_launch = bool(lib.neptune_hip_last_launch(C.byref(launched)))
+
+    # ---- the run verifies itself: one more step from the freshly filled field, sampled planes against the oracle -------
+    verified = None
+    if not args.no_verify:
+        dog.stage("self-check against the oracle", 600)
+        verified = verify_against_oracle(args, torch, dist, world, rank, sl, bufs, refill, step, body_name, gshape, esize,
+                                         plane_cells, int(launched.chunk) if have_launch else 0, ranks_agree)
+        dog.done()
+        if verified is None:
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            sys.exit(5)
+
+    # ---- the other single-GPU BASELINE configurations ------------------------------------------------------------------
+    configs = None
+    if extra:
+        dog.stage("the other single-GPU configurations", 900)
+        del op, sharded
+        bufs.clear()
+        torch.cuda.empty_cache()
+        configs = []
+        for name in EXTRA_CONFIGS:
+            configs.append(run_config(name, nh_apply, fields, slab_mod, lib, _capi, torch, chain=1))
+        configs.append(run_config("3d7_1024", nh_apply, fields, slab_mod, lib, _capi, torch, chain=3))
+        dog.done()
 
     if rank == 0:
         cells = 1
@@ -396,26 +632,18 @@ def main():
         # input cell read once, every result cell written once; one launch covers
         # this rank's owned cells.  Duration = HIP-event time on the launch stream / launches.
         own_cells = sl.n_own * plane_cells
-        if world == 1:
-            alg_bytes = 2.0 * own_cells * esize
-            kern_ms = ev_ms / args.steps
-        else:
-            alg_bytes = 2.0 * own_cells * esize
-            kern_ms = ev_ms / args.steps  # per step on this rank's compute stream (interior + edges + waits)
+        alg_bytes = 2.0 * own_cells * esize
+        kern_ms = ev_ms / args.steps       # N>1: per step on this rank's compute stream (interior + edges + waits)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        plan = nh_apply.plan_builtin(builtin_body, [bufs[0]], bufs[1], sharded.bounds, region=sharded._own_region(), cfg=cfg)
-        import ctypes as C
-        g_own = nh_apply.geom_for([bufs[0]], bufs[1], sharded.bounds, sharded.interior if (world > 1 and sharded.interior is not None)
-                                  else sharded._own_region())
-        vidx = lib.neptune_hip_apply_builtin_variant(builtin_body, C.byref(g_own), C.byref(cfg))   # the dominant launch's tile
-        vname = lib.neptune_hip_march_variant_name(rank_nd, vidx).decode() if plan == _capi.KERNEL_MARCH else ""
+        kname = lib.neptune_hip_kernel_name(int(launched.kernel)).decode() if have_launch else ""
+        vname = (lib.neptune_hip_march_variant_name(rank_nd, int(launched.variant)).decode()
+                 if have_launch and int(launched.kernel) == _capi.KERNEL_MARCH else "")
         # HBM traffic cannot be counted live (PMC needs rocprofv3): report the per-launch bytes of
         # the matching kernel/shape from the committed separate-pass profile, or null
         traffic, traffic_src = args.hbm_traffic_bytes, "command line" if args.hbm_traffic_bytes else None
         tfile = REPO / "profiles" / "traffic.json"
         if traffic is None and world == 1 and tfile.exists():
-            key = f"{args.workload}|{lib.neptune_hip_kernel_name(plan).decode()}|{vname}"
-            ent = json.loads(tfile.read_text()).get("entries", {}).get(key)
+            ent = json.loads(tfile.read_text()).get("entries", {}).get(f"{args.workload}|{kname}|{vname}")
             if ent:
                 traffic, traffic_src = ent["traffic_bytes_per_launch"], ent["source"]
         out = {
@@ -435,18 +663,23 @@ def main():
                 "workload": f"{rank_nd}-D {points}-point Laplacian apply, "
                             f"{'x'.join(str(n) for n in gshape)} {'fp64' if esize == 8 else 'fp32'}, "
                             f"interior bounds, copy-through boundary, ping-pong fields",
-                "fixture": {"lap3d7_f64": "apply-3d-7pt.mlir", "lap2d5_f64": "apply-2d-5pt.mlir",
-                            "lap3d27_f32": "apply-3d-27pt.mlir"}[body_name],
+                "fixture": FIXTURE[body_name] + (" (the committed text regenerated at this size by tools/make_stencil_mlir.py; "
+                                                 "tests/test_lowering.py pins generator == committed file)"),
                 "emulated_rank": args.emulate_rank or None,
-                "decomposition": f"dim-0 slabs x{world}, 1 halo plane/neighbour over RCCL"
-                                 + ("" if args.no_overlap else ", overlapped with interior") if world > 1 else "single GPU",
-                "kernel": lib.neptune_hip_kernel_name(plan).decode(),
+                "decomposition": (f"dim-0 slabs x{world}, 1 halo plane/neighbour" + ("" if args.no_overlap else ", exchange overlapped with interior")
+                                  if world > 1 else "single GPU"),
+                "kernel": kname,
                 "variant": vname,
-                "chunk": int(cfg.chunk),
+                "chunk": int(launched.chunk) if have_launch else None,
                 "autotuned": autotuned,
                 "halo_transport": transport,
+                "halo_transports": verdicts or None,
+                "step_breakdown_ms": breakdown,
                 "host_enqueue_us_per_step": t_enqueued * 1e6 / args.steps,
                 "body": "lowered module (NeptuneIR text -> emitter -> hipcc)" if args.lowered else "library built-in (same statements)",
+                "verified": verified,
+                "watchdog_stages_s": dog.history,
+                "configs": configs,
             },
             "hbm_GBps": achieved * world if world > 1 else achieved,
             "roofline": {
@@ -471,14 +704,141 @@ def main():
 
     lib.neptune_hip_event_destroy(ev0)
     lib.neptune_hip_event_destroy(ev1)
+    dog.stage("shutdown", 120)
     if world > 1:
         dist.barrier()
-    del op, sharded                      # the C-side plan (its stream and events) before its communicator
-    if rccl_comm is not None:
-        torch.cuda.synchronize()
-        rccl_comm.close()
+    op = sharded = None                  # the C-side plan (its stream and events) before its communicator
+    ops.clear()
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    for c in comms.values():
+        if c is not None:
+            c.close()
     if world > 1:
         dist.destroy_process_group()
+    dog.done()
+
+
+def verify_against_oracle(args, torch, dist, world, rank, sl, bufs, refill, step, body_name, gshape, esize, plane_cells, chunk,
+                          ranks_agree):
+    """One more step of exactly the timed configuration from the freshly filled field; sampled planes of this rank's owned
+    part (the global boundary, the slab cuts, chunk seams, the middle) compared bit for bit with the numpy oracle run on
+    the three input planes each needs (regenerated on the host from the same hash).  The oracle is the checker here, never
+    the thing measured.  Returns the report string, or None after printing the mismatch."""
+    import numpy as np
+    sys.path.insert(0, str(REPO / "tests"))
+    import helpers
+    kind = KIND[body_name]
+    npdt = np.float64 if esize == 8 else np.float32
+    refill()
+    step(0)                                       # reads bufs[0], writes bufs[1] (also with --fixed-input)
+    torch.cuda.synchronize()
+    lo, hi = sl.owned_planes()
+    n0 = gshape[0]
+    want_planes = {sl.start, sl.start + 1, sl.stop - 2, sl.stop - 1, (sl.start + sl.stop) // 2}
+    for c in (chunk, 2 * chunk):                  # chunk seams of the dominant launch, counted from its first plane
+        first = sl.start + (1 if sl.r_lo else 0)
+        if chunk and first + c < sl.stop:
+            want_planes |= {first + c - 1, first + c}
+    planes = sorted(p for p in want_planes if sl.start <= p < sl.stop)
+    row_shape = tuple(gshape[1:])
+    bad = []
+    for p in planes:                              # p: global plane index
+        got = bufs[1].tensor[lo + (p - sl.start)].detach().cpu().numpy()
+        if p == 0 or p == n0 - 1:                 # copy-through: the input plane itself
+            want = helpers.hash_field(row_shape, npdt, SEED, index_offset=p * plane_cells)
+        else:
+            slab3 = helpers.hash_field((3,) + row_shape, npdt, SEED, index_offset=(p - 1) * plane_cells)
+            want = helpers.oracle_entry(kind, slab3)[1]
+        if not helpers.bits_equal(got, want):
+            bad.append(p)
+            print(f"[bench] rank {rank}: VERIFY: plane {p} differs from the oracle\n" + helpers.mismatch_report(got, want),
+                  file=sys.stderr, flush=True)
+    ok = ranks_agree(not bad)
+    if not ok:
+        return None
+    return (f"{len(planes)} planes per rank bit-exact vs the oracle (one step of the timed configuration from the freshly filled "
+            f"field; rank 0 checked global planes {planes})")
+
+
+def run_config(name, nh_apply, fields, slab_mod, lib, _capi, torch, chain=1, steps=200):
+    """One of BASELINE.json's other single-GPU configurations: the workload's fixture through the lowering (text ->
+    emitter -> hipcc -> geometry-level entry), plan-time tuned like the headline, 1 s clock ramp on real data, `steps`
+    ping-pong steps timed with HIP events on the launch stream.  chain = 3: the step loop at three applies per pass over
+    HBM (neptune_hip_step_loop_chain; bit-identical to one apply per launch)."""
+    from neptune_hip import lowering as nh_lowering
+    import make_stencil_mlir
+    body_name, shape, esize, points = WORKLOADS[name]
+    module = nh_lowering.compile_module(fixture_text(body_name, shape))
+    entry = module.geom_entry(make_stencil_mlir.KINDS[KIND[body_name]][2])
+    dtype = nh_apply.BODY_DTYPE[nh_apply.BODY_BY_NAME[body_name]]
+    nd = len(shape)
+    bounds = ([1] * nd, [n - 1 for n in shape])
+    a = fields.DeviceField([0] * nd, list(shape), dtype)
+    b = fields.DeviceField([0] * nd, list(shape), dtype)
+    a.fill_hash(SEED)
+    b.tensor.zero_()
+    cells = 1
+    for n in shape:
+        cells *= n
+    alg_bytes = 2.0 * cells * esize
+    st = fields.current_stream_ptr()
+    ev0, ev1 = lib.neptune_hip_event_create(), lib.neptune_hip_event_create()
+    launched = _capi.LaunchCfg()
+    if chain == 1:
+        cfg, _ = nh_apply.autotune_builtin(entry, [a], b, bounds)
+        if int(cfg.kernel) == _capi.KERNEL_AUTO:
+            cfg = None
+
+        def run(n):
+            for s in range(n):
+                nh_apply.apply_builtin(entry, [a if s % 2 == 0 else b], b if s % 2 == 0 else a, bounds, cfg=cfg)
+    else:
+        cfg = None
+
+        def run(n):
+            nh_apply.step_loop(entry, a, b, bounds, n)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 1.0:         # clock ramp on real data (restored every 12 steps)
+        run(12)
+        a.fill_hash(SEED)
+        torch.cuda.synchronize()
+    a.fill_hash(SEED)
+    b.tensor.zero_()
+    run(6)
+    torch.cuda.synchronize()
+    if chain == 1:
+        lib.neptune_hip_last_launch(C.byref(launched))
+    a.fill_hash(SEED)
+    torch.cuda.synchronize()
+    lib.neptune_hip_event_record(ev0, st)
+    run(steps)
+    lib.neptune_hip_event_record(ev1, st)
+    torch.cuda.synchronize()
+    ms = lib.neptune_hip_event_elapsed_ms(ev0, ev1) / steps
+    lib.neptune_hip_event_destroy(ev0)
+    lib.neptune_hip_event_destroy(ev1)
+    gbps = alg_bytes / (ms * 1e-3) / 1e9
+    res = {
+        "workload": f"{nd}-D {points}-point Laplacian apply, {'x'.join(map(str, shape))} {'fp64' if esize == 8 else 'fp32'}"
+                    + ("" if chain == 1 else f", step loop at {chain} applies per pass over HBM"),
+        "name": name if chain == 1 else f"{name}_chain{chain}",
+        "ms": ms,                                  # per step (= per apply)
+        "hbm_GBps": gbps,                          # 2 N sizeof(T) per step / ms: one-apply-per-pass accounting
+        "frac": gbps / HBM_PEAK_GBPS,
+        "steps": steps,
+        "body": "lowered module",
+    }
+    if chain == 1:
+        res["variant"] = lib.neptune_hip_march_variant_name(nd, int(launched.variant)).decode() if int(launched.kernel) == _capi.KERNEL_MARCH else ""
+        res["chunk"] = int(launched.chunk)
+    else:
+        res["variant"], res["chunk"] = f"apply_march2 NS={chain}", None
+        res["note"] = "frac counts 2 N sizeof(T) per STEP; the kernel moves ~2.35 field passes per three steps, so values above 1 are expected"
+    del a, b
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

@@ -366,6 +366,31 @@ double neptune_hip_time_apply_fn(neptune_hip_apply_fn fn, const neptune_hip_appl
 int neptune_hip_autotune_fn(neptune_hip_apply_fn fn, int num_variants, const neptune_hip_apply_geom_t *g,
                             const void *const *in, void *out, void *stream, int reps,
                             neptune_hip_launch_cfg_t *best, double *best_ms);
+/* ---- launch wisdom: measured launch choices, remembered across processes --------------------------------
+ * An apply launched without an explicit configuration (cfg NULL or all-automatic) on a field of
+ * NEPTUNE_HIP_TUNE_MIN_CELLS cells (default 2^24) or more measures ONCE which of its march tiles and chunk lengths is
+ * fastest for exactly that (body, geometry): the first launch times the candidates (it synchronises the stream; every
+ * candidate writes the same bits), later launches of the process reuse the choice, and the choice is appended to a
+ * wisdom file so that every later PROCESS on the same device reuses it without timing anything (FFTW's wisdom, for
+ * stencil launches).  File: $NEPTUNE_HIP_WISDOM, else <$NEPTUNE_CACHE_DIR or ~/.neptune/cache>/wisdom_v1.txt -- next
+ * to the module cache; NEPTUNE_HIP_WISDOM= (empty) keeps choices in the process only.  NEPTUNE_HIP_TUNE=0 switches the
+ * measuring off (fixed automatic tiles), NEPTUNE_HIP_TUNE=1 measures fields of any size.  A launch inside a stream
+ * capture never measures.  Keys name the kernel build, the module and body, the element type and everything of the
+ * geometry the launcher looks at; the library adds the device (name, architecture, CU count).
+ * lookup: 1 = found (*cfg filled), 0 = unknown.  store: appends one line; 0 on success.
+ * The reference has nothing to tune (one scalar loop nest, DataflowLowering.cpp:289-310). */
+int neptune_hip_wisdom_lookup(const char *key, neptune_hip_launch_cfg_t *cfg);
+int neptune_hip_wisdom_store(const char *key, const neptune_hip_launch_cfg_t *cfg, double ms);
+/* the wisdom file of this process ("" when disabled); pointer valid for the process lifetime */
+const char *neptune_hip_wisdom_path(void);
+/* counters of this process: out[0] = first-use measurements made, out[1] = choices taken from the wisdom file,
+ * out[2] = choices appended to it */
+void neptune_hip_tune_stats(int64_t out[3]);
+/* What the most recent apply launch of the calling thread really ran: kernel, march tile, planes per workgroup
+ * (chunk as launched, never 0 for the march kernel).  Launchers call _note_launch; returns 0 if nothing was launched yet. */
+void neptune_hip_note_launch(int kernel, int variant, int chunk);
+int neptune_hip_last_launch(neptune_hip_launch_cfg_t *out);
+
 /* Plain 16-byte-per-lane device copy, timed the same way: the measured HBM ceiling.
  * mode selects the copy kernel shape (0 .. neptune_hip_copy_mode_count()-1: grid-stride, or
  * 1/2/4/8 loads in flight per lane with optional non-temporal loads/stores). */
@@ -383,40 +408,71 @@ double neptune_hip_event_elapsed_ms(void *start, void *stop);
 void neptune_hip_stream_wait_event(void *stream, void *ev);
 
 /* ------------------------------------------------------------------------------------
- * 8. slab decomposition across the GPUs of a node: halo exchange over RCCL, overlapped with the interior
+ * 8. slab decomposition across the GPUs of a node: halo exchange overlapped with the interior
  *    (the reference has no counterpart -- every PETSc object lives on PETSC_COMM_SELF,
  *    NeptunePETScRuntime.cpp:136,244,257).  One process per GPU.  Rank g owns planes [start_g, stop_g) of dim 0
  *    and keeps `radius` ghost planes per existing neighbour in the SAME dense buffer:
  *        local buffer = [ r_lo ghost planes | n_own owned planes | r_hi ghost planes ] x plane
- *    so a halo is one contiguous run of memory, sent and received in place (ncclSend/ncclRecv, grouped, on a
- *    communication stream).  No periodic wrap: at the global boundary r_lo / r_hi are 0 and the apply's copy-through
- *    semantics hold (DataflowLowering.cpp:283-287, 382-410).
- *    RCCL is loaded at the first call (dlopen librccl.so.1, reusing a copy already in the process); programs that
- *    never call these entry points never load it.  Failures return NEPTUNE_HIP_ECOMM / NULL with the text in
- *    neptune_hip_slab_last_error() -- they never fall back to another transport.
+ *    so a halo is one contiguous run of memory, sent and received in place.  No periodic wrap: at the global boundary
+ *    r_lo / r_hi are 0 and the apply's copy-through semantics hold (DataflowLowering.cpp:283-287, 382-410).
+ *    Two transports behind one communicator type:
+ *      NEPTUNE_HIP_TRANSPORT_RCCL  ncclSend/ncclRecv, grouped, on a communication stream.  RCCL is loaded at the first
+ *          call (dlopen librccl.so.1, reusing a copy already in the process); programs that never call these entry
+ *          points never load it.
+ *      NEPTUNE_HIP_TRANSPORT_PEER  the ranks of ONE node: every rank pushes its edge planes into its neighbour's ghost
+ *          planes with hipMemcpyAsync through a mapping of the neighbour's buffer (hipIpcOpenMemHandle) -- SDMA engines
+ *          over xGMI between two devices, no CU moves data -- and two one-wave kernels per exchange carry the
+ *          "ghost planes free" / "planes landed" handshake through counters in a shared-memory segment
+ *          (csrc/runtime/slab_peer.hpp).  Two processes may share one device on this transport.  Buffers exchanged
+ *          through it must stay allocated while the communicator lives (their mappings are cached).
+ *    Failures return NEPTUNE_HIP_ECOMM / NULL with the text in neptune_hip_slab_last_error() -- they never fall back to
+ *    another transport.  Either transport issues work on a stream of its own: synchronise the compute stream (or wait
+ *    for the plan's completion) before issuing collectives of ANOTHER communicator library on the same device
+ *    (torch.distributed's, say) -- two communicators progressing concurrently can deadlock.
+ *    Multi-rank runs of the RCCL transport between two devices are unverified on the authors' hardware (one-GPU boxes:
+ *    loop-back and two-process tests only); a start-up exchange check like bench.py's is recommended.
  * ---------------------------------------------------------------------------------- */
 #define NEPTUNE_HIP_SLAB_ID_BYTES 128
+#define NEPTUNE_HIP_TRANSPORT_RCCL 0
+#define NEPTUNE_HIP_TRANSPORT_PEER 1
 typedef struct neptune_hip_slab_comm neptune_hip_slab_comm_t;
 typedef struct neptune_hip_slab_plan neptune_hip_slab_plan_t;
 
-/* rank 0 makes the id (ncclGetUniqueId) and hands the 128 bytes to every rank by any means */
+/* rank 0 makes the id (RCCL: ncclGetUniqueId; peer: 128 random bytes naming the node's shared segment) and hands the
+ * 128 bytes to every rank by any means.  The plain names are the RCCL transport. */
 int neptune_hip_slab_unique_id(void *id_out);
-/* collective over the `world` ranks (ncclCommInitRank on the current device); id may be NULL when world == 1 */
+int neptune_hip_slab_unique_id_ex(int transport, void *id_out);
+/* collective over the `world` ranks (RCCL: ncclCommInitRank on the current device; peer: every rank maps the segment
+ * and waits for the others, bounded by NEPTUNE_HIP_PEER_TIMEOUT_S, default 20 s); id may be NULL when world == 1 */
 neptune_hip_slab_comm_t *neptune_hip_slab_comm_create(const void *id, int rank, int world);
+neptune_hip_slab_comm_t *neptune_hip_slab_comm_create_ex(int transport, const void *id, int rank, int world);
 void neptune_hip_slab_comm_destroy(neptune_hip_slab_comm_t *comm);
 const char *neptune_hip_slab_last_error(void);
+/* "rccl" / "peer" */
+const char *neptune_hip_slab_comm_transport(const neptune_hip_slab_comm_t *comm);
+/* NEPTUNE_HIP_OK, or NEPTUNE_HIP_ECOMM once a device-side wait of the peer transport has timed out (a neighbour died
+ * or fell more than the timeout behind): every exchange since then left stale ghost planes.  Never blocks. */
+int neptune_hip_slab_comm_status(neptune_hip_slab_comm_t *comm);
 
 /* Refresh the ghost planes of one local buffer on `stream`: the first r_lo owned planes go to peer_lo and its last
  * planes arrive in my lower ghosts; likewise r_hi / peer_hi above (a side with 0 ghost planes is skipped, its peer is
- * ignored).  Asynchronous.  peer == own rank is allowed (a loop-back used by the single-GPU tests). */
+ * ignored).  Asynchronous.  peer == own rank is allowed (a loop-back used by the single-GPU tests: RCCL matches the
+ * two send/receive pairs in order, so the lower ghosts receive the rank's FIRST owned planes; the peer transport
+ * pushes to the neighbour's opposite side, so they receive its LAST owned planes -- a periodic wrap).
+ * _many: the ghost planes of `nfields` buffers (<= NEPTUNE_HIP_MAX_INPUTS) in one grouped exchange / one handshake. */
 int neptune_hip_halo_exchange(neptune_hip_slab_comm_t *comm, void *field, size_t plane_bytes, int64_t n_own,
                               int r_lo, int r_hi, int peer_lo, int peer_hi, void *stream);
+int neptune_hip_halo_exchange_many(neptune_hip_slab_comm_t *comm, void *const *fields, const size_t *plane_bytes,
+                                   int nfields, int64_t n_own, int r_lo, int r_hi, int peer_lo, int peer_hi,
+                                   void *stream);
 
 /* One apply over this rank's slab, planned once.  `fn`: a lowered apply's geometry-level entry, or NULL to use
  * built-in body `body`.  `local`: the geometry of the LOCAL buffers (boxes include the ghost planes; apply.bounds
  * already clipped to the owned planes; the region is ignored).  radius = the apply's reach along dim 0.
  * neptune_hip_slab_apply then runs, per call:
  *     comm stream   : wait for the input on `compute_stream`, exchange the ghost planes of EVERY input
+ *                     (a stream of the greatest priority the device offers: the exchange is dispatched ahead of the
+ *                     interior grid, which fills every CU)
  *     compute stream: interior planes (those that need no ghost data)                 -- overlaps the exchange
  *     compute stream: wait for the exchange, then the `radius` edge planes per side that has a neighbour
  * overlap = 0 makes the interior wait for the exchange as well (debugging).  Asynchronous on compute_stream. */
@@ -427,6 +483,17 @@ neptune_hip_slab_plan_t *neptune_hip_slab_plan_create(neptune_hip_slab_comm_t *c
 int neptune_hip_slab_apply(neptune_hip_slab_plan_t *plan, const void *const *in, void *out, void *compute_stream,
                            int overlap);
 void neptune_hip_slab_plan_destroy(neptune_hip_slab_plan_t *plan);
+/* Where a sharded step spends its time.  _timing(plan, 1) makes every following neptune_hip_slab_apply record five
+ * timed events (a ring of 64 steps; no synchronisation is added); _timing_read waits for the recorded steps and
+ * returns their averages in milliseconds:
+ *   out[0] exchange   (communication stream: input ready -> ghost planes landed)
+ *   out[1] interior   (compute stream: the interior launch)
+ *   out[2] edge wait  (how long after the interior's end the exchange ended; 0 when it was hidden behind it)
+ *   out[3] edges      (the edge launches)
+ *   out[4] step       (interior start -> edges done)
+ *   out[5] steps averaged */
+int neptune_hip_slab_plan_timing(neptune_hip_slab_plan_t *plan, int on);
+int neptune_hip_slab_plan_timing_read(neptune_hip_slab_plan_t *plan, double out[6]);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,9 @@
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <typeinfo>
 
 #include "../../../include/neptune_hip.h"
 #include "apply_common.hpp"
@@ -619,6 +622,7 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
       P.rI0 = (int32_t)rlb[0]; P.rI1 = (int32_t)rub[0];
     }
     launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
+    neptune_hip_note_launch(NEPTUNE_HIP_KERNEL_MARCH, variant, P.chunk);
     if (P.N2 % (16 / (int)sizeof(T)) != 0) {
       // ragged rows: cells [Ks, N2) of every row of the region -- fewer than 3*VK per row -- through the
       // flat direct kernel (lanes run down the rows: strided, but a fraction of a percent of the field)
@@ -629,55 +633,110 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     return NEPTUNE_HIP_OK;
   }
 
+  neptune_hip_note_launch(NEPTUNE_HIP_KERNEL_DIRECT, -1, 0);
   return launch_direct<Body, T, RANK, NIN>(body, g, in, out, stream, cfg && (cfg->flags & NEPTUNE_HIP_FLAG_DIRECT_FLAT));
 }
 
-// ---- measured tile choice at first use (NEPTUNE_HIP_TUNE=1) ----------------------------------------------
-// FFTW_MEASURE for applies: the first launch of a (body, geometry) with no explicit configuration times every
-// march tile this translation unit holds (the runtime library: all of them; a lowered module: the defaults,
-// or all with -DNEPTUNE_HIP_FULL_VARIANTS=1) with a few chunk lengths and keeps the fastest for later launches
-// of the same geometry.  Every candidate computes the same bits into `out`, so the timed launches are
-// harmless; they synchronise the stream, which is why this is opt-in and skipped during stream capture.
-inline bool tune_enabled() {
-  static const bool on = [] {
+// ---- measured launch choice at first use, remembered as wisdom -----------------------------------------------
+// FFTW_MEASURE for applies, on by default for fields large enough to measure: the first launch of a (body, geometry)
+// with no explicit configuration looks the choice up in the wisdom file (include/neptune_hip.h "launch wisdom"); if it
+// is not there it times the default march tiles this translation unit holds with a few chunk lengths, keeps the fastest
+// for later launches of the same geometry and appends it to the file, so that every later process starts from it without
+// timing anything.  Every candidate computes the same bits into `out`, so the timed launches are harmless; they
+// synchronise the stream, which is why a launch inside a stream capture never measures.
+//   NEPTUNE_HIP_TUNE=0  no measuring, fixed automatic tiles      NEPTUNE_HIP_TUNE=1  measure fields of any size
+//   NEPTUNE_HIP_TUNE_MIN_CELLS  smallest launch region that is measured by default (2^24 cells)
+#ifndef NEPTUNE_HIP_MODULE_ID
+#define NEPTUNE_HIP_MODULE_ID "lib"   // emitted modules define it: a hash of their body functors
+#endif
+#ifndef NEPTUNE_HIP_BUILD_ID
+#define NEPTUNE_HIP_BUILD_ID "dev"    // the build defines it: a hash of the kernel headers this code was compiled from
+#endif
+inline int tune_mode() {   // 0 = never, 1 = large launches (default), 2 = every launch
+  static const int mode = [] {
     const char* e = getenv("NEPTUNE_HIP_TUNE");
-    return e && *e && *e != '0';
+    if (!e || !*e) return 1;
+    return *e == '0' ? 0 : 2;
   }();
-  return on;
+  return mode;
 }
+inline int64_t tune_min_cells() {
+  static const int64_t n = [] {
+    const char* e = getenv("NEPTUNE_HIP_TUNE_MIN_CELLS");
+    const long long v = (e && *e) ? atoll(e) : 0;
+    return (int64_t)(v > 0 ? v : (1LL << 24));
+  }();
+  return n;
+}
+inline bool tune_enabled() { return tune_mode() == 2; }
+// how many tiles of each rank's table are the defaults (what a lowered module holds)
+#define NEPTUNE_MV_ONE(idx, RJ, WJ, WK, DPP, NT, PF, NTL, LDSJ, JK, JHL, KD, PLN, name) +1
+constexpr int kNumMarch3Default = 0 NEPTUNE_MARCH3_DEFAULT(NEPTUNE_MV_ONE);
+constexpr int kNumMarch2Default = 0 NEPTUNE_MARCH2_DEFAULT(NEPTUNE_MV_ONE);
+#undef NEPTUNE_MV_ONE
 
 template <class Body, class T, int RANK, int NIN, class FP>
 inline neptune_hip_launch_cfg_t tune_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
-                                           hipStream_t stream) {
+                                           hipStream_t stream, double* best_ms_out = nullptr) {
   neptune_hip_launch_cfg_t best = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
   if (plan_apply<T, RANK, NIN, FP>(g, in, out, &best) != NEPTUNE_HIP_KERNEL_MARCH) return best;
-  hipEvent_t e0, e1;
+  hipEvent_t e0, e1, e2;
   NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
   NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+  NEPTUNE_HIP_CHECK(hipEventCreate(&e2));
+  float best_ms = -1.f;
+  // one launch alone first (it also pays one-off costs); a candidate whose first launch already takes 1.4x the best
+  // average so far is dropped without its repetitions (the spilling tiles of a fat body: 2-6x)
   auto time_cfg = [&](const neptune_hip_launch_cfg_t& c) -> float {
-    if (launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c) != NEPTUNE_HIP_OK) return -1.f;
     NEPTUNE_HIP_CHECK(hipEventRecord(e0, stream));
-    for (int r = 0; r < 3; ++r) launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c);
+    if (launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c) != NEPTUNE_HIP_OK) return -1.f;
     NEPTUNE_HIP_CHECK(hipEventRecord(e1, stream));
     NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
-    float ms = 0;
-    NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    float first = 0, ms = 0;
+    NEPTUNE_HIP_CHECK(hipEventElapsedTime(&first, e0, e1));
+    if (best_ms > 0 && first > 1.4f * best_ms) return first;
+    for (int r = 0; r < 3; ++r) launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c);
+    NEPTUNE_HIP_CHECK(hipEventRecord(e2, stream));
+    NEPTUNE_HIP_CHECK(hipEventSynchronize(e2));
+    NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e1, e2));
+    return ms / 3.f;
+  };
+  auto try_cfg = [&](const neptune_hip_launch_cfg_t& c) {
+    const float ms = time_cfg(c);
+    if (ms > 0 && (best_ms <= 0 || ms < best_ms)) { best_ms = ms; best = c; }
     return ms;
   };
-  float best_ms = time_cfg(best);
-  const int chunks3[] = {0, 64, 128}, chunks2[] = {0, 32};
-  for (int v = 0; v < march_variant_count(RANK); ++v) {
-    const bool tile2 = RANK == 2 && march_variant(RANK, v)->jk;
+  try_cfg(best);
+  try_cfg(best);   // the very first launches of a process run on clocks that are still ramping: time the automatic choice twice
+  // stage 1: every default tile on its automatic chunk length; stage 2: chunk lengths on the two fastest tiles
+  // (a module built with NEPTUNE_HIP_FULL_VARIANTS=1 asked for every tile; the runtime library holds them all for the
+  // sweeps and parity tests, its first-use choice stays among the defaults)
+  constexpr int kDefaults = RANK == 3 ? kNumMarch3Default : (RANK == 2 ? kNumMarch2Default : 1);
+  const bool all_tiles = NEPTUNE_HIP_FULL_VARIANTS && strcmp(NEPTUNE_HIP_MODULE_ID, "lib") != 0;
+  const int nv = (all_tiles || march_variant_count(RANK) < kDefaults) ? march_variant_count(RANK) : kDefaults;
+  int top[2] = {-1, -1};
+  float top_ms[2] = {-1.f, -1.f};
+  for (int v = 0; v < nv; ++v) {
+    const float ms = try_cfg({NEPTUNE_HIP_KERNEL_MARCH, v, 0, 0});
+    if (ms <= 0) continue;
+    if (top_ms[0] < 0 || ms < top_ms[0]) { top[1] = top[0]; top_ms[1] = top_ms[0]; top[0] = v; top_ms[0] = ms; }
+    else if (top_ms[1] < 0 || ms < top_ms[1]) { top[1] = v; top_ms[1] = ms; }
+  }
+  const int64_t planes = RANK == 1 ? 1 : g->region_ub[0] - g->region_lb[0];
+  const int chunks3[] = {32, 64, 128, 256, 512}, chunks2[] = {32};
+  for (int t = 0; t < 2; ++t) {
+    if (top[t] < 0) continue;
+    const bool tile2 = RANK == 2 && march_variant(RANK, top[t])->jk;
+    if (RANK == 1 || tile2) continue;   // one plane: no chunk length to choose
     const int* chunks = RANK == 3 ? chunks3 : chunks2;
-    const int nc = RANK == 3 ? 3 : (RANK == 2 && !tile2 ? 2 : 1);
-    for (int c = 0; c < nc; ++c) {
-      const neptune_hip_launch_cfg_t cand = {NEPTUNE_HIP_KERNEL_MARCH, v, chunks[c], 0};
-      const float ms = time_cfg(cand);
-      if (ms > 0 && (best_ms <= 0 || ms < best_ms)) { best_ms = ms; best = cand; }
-    }
+    const int nc = RANK == 3 ? 5 : 1;
+    for (int c = 0; c < nc; ++c)
+      if (chunks[c] < planes) try_cfg({NEPTUNE_HIP_KERNEL_MARCH, top[t], chunks[c], 0});
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(e2);
+  if (best_ms_out) *best_ms_out = best_ms;
   return best;
 }
 
@@ -685,19 +744,21 @@ template <class Body, class T, int RANK, int NIN, class FP>
 inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                         hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
   const bool free_choice = !cfg || (cfg->kernel == NEPTUNE_HIP_KERNEL_AUTO && cfg->variant < 0 && cfg->chunk == 0 && cfg->flags == 0);
-  if (free_choice && tune_enabled() && g) {
+  if (free_choice && tune_mode() != 0 && g && FP::MARCH_OK) {
     // one table per body (this function is instantiated per Body); key: everything of the geometry that the
     // launcher looks at, plus the 16-byte alignment of the buffers
     static std::mutex mu;
     static std::map<std::array<int64_t, 20>, neptune_hip_launch_cfg_t> table;
     std::array<int64_t, 20> key{};
     int n = 0;
+    int64_t cells = 1;
     for (int d = 0; d < 3; ++d) {
       key[n++] = d < RANK ? g->out_ub[d] - g->out_lb[d] : 1;
       key[n++] = d < RANK ? g->lb[d] - g->out_lb[d] : 0;
       key[n++] = d < RANK ? g->ub[d] - g->out_lb[d] : 1;
       key[n++] = d < RANK ? g->region_lb[d] : 0;
       key[n++] = d < RANK ? g->region_ub[d] : 1;
+      if (d < RANK) cells *= (g->region_ub[d] > g->region_lb[d] ? g->region_ub[d] - g->region_lb[d] : 0);
     }
     int64_t align = ((uintptr_t)out % 16 == 0);
     for (int k = 0; k < NIN; ++k) {
@@ -705,7 +766,8 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
       for (int d = 0; d < RANK; ++d) align = align * 2 + (g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d]);
     }
     key[n++] = align;
-    neptune_hip_launch_cfg_t tuned;
+    const neptune_hip_launch_cfg_t untuned = {NEPTUNE_HIP_KERNEL_AUTO, -1, 0, 0};
+    neptune_hip_launch_cfg_t tuned = untuned;
     bool have = false;
     {
       std::lock_guard<std::mutex> lk(mu);
@@ -713,18 +775,38 @@ inline int launch_apply(const Body& body, const neptune_hip_apply_geom_t* g, con
       if (it != table.end()) { tuned = it->second; have = true; }
     }
     if (!have) {
-      // measuring synchronises the stream: not possible while it is being captured into a graph (the step
-      // loop launches once outside capture first, so its graph still gets the measured choice)
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
-      if (cs == hipStreamCaptureStatusNone && geom_validate(g) == NEPTUNE_HIP_OK) {
-        tuned = tune_apply<Body, T, RANK, NIN, FP>(body, g, in, out, stream);
+      bool decided = true;   // false: leave the table alone (a capture is in progress: measure at the next plain launch)
+      if ((tune_mode() == 2 || cells >= tune_min_cells()) && geom_validate(g) == NEPTUNE_HIP_OK &&
+          plan_apply<T, RANK, NIN, FP>(g, in, out, &untuned) == NEPTUNE_HIP_KERNEL_MARCH) {
+        // wisdom key: kernel build, module, body type, element size, rank, inputs, then the table key
+        std::string wkey = std::string(NEPTUNE_HIP_BUILD_ID) + "|" + NEPTUNE_HIP_MODULE_ID + "|" + typeid(Body).name() + "|" +
+                           std::to_string(sizeof(T)) + "|" + std::to_string(RANK) + "|" + std::to_string(NIN);
+        for (int i = 0; i < n; ++i) wkey += (i ? "," : "|") + std::to_string(key[i]);
+        if (neptune_hip_wisdom_lookup(wkey.c_str(), &tuned) &&
+            (tuned.kernel != NEPTUNE_HIP_KERNEL_MARCH || (tuned.variant >= 0 && tuned.variant < march_variant_count(RANK)))) {
+          // (a choice this translation unit cannot run -- a tile index beyond its table -- is measured again)
+        } else {
+          tuned = untuned;
+          // measuring synchronises the stream: not possible while it is being captured into a graph (the step
+          // loop launches once outside capture first, so its graph still gets the measured choice)
+          hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+          if (cs == hipStreamCaptureStatusNone) {
+            double ms = 0;
+            tuned = tune_apply<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &ms);
+            (void)neptune_hip_wisdom_store(wkey.c_str(), &tuned, ms);
+          } else {
+            decided = false;
+          }
+        }
+      }
+      if (decided) {
         std::lock_guard<std::mutex> lk(mu);
         table[key] = tuned;
-        have = true;
       }
     }
-    if (have) return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &tuned);
+    const bool is_tuned = tuned.kernel != NEPTUNE_HIP_KERNEL_AUTO || tuned.variant >= 0 || tuned.chunk != 0;
+    if (is_tuned) return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &tuned);
   }
   return launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, cfg);
 }

@@ -1,13 +1,25 @@
 // capi.cpp -- extern "C" entry points of libneptune_lowering.so (bound by the Python frontend
 // through ctypes; declared for C callers in include/neptune_lowering.h).
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <exception>
+#include <filesystem>
 #include <fstream>
 #include <sstream>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "lowering.h"
+
+extern char** environ;
 
 using namespace neptune_lowering;
 
@@ -56,6 +68,65 @@ std::string report_json(const LowerInfo& info) {
   }
   o << "]}";
   return o.str();
+}
+// Run `argv` as a child process with stdout/stderr in `log_path` and wait for it.  The child's environment is the
+// caller's minus everything a profiler or tool injects into a process (LD_PRELOAD, ROCP* / ROCPROFILER* / HSA_TOOLS_*):
+// under `rocprofv3 --pmc` the preloaded library initialises the GPU in every process that inherits it, and hipcc execs
+// clang, lld, ... in turn -- a chain of exec hops from GPU-initialised processes, which this pool forbids.  The compiler
+// needs none of those variables.  Returns the exit status, or -1 (why in `err`).
+bool tool_variable(const char* kv) {
+  static const char* const prefixes[] = {"LD_PRELOAD=", "ROCP", "ROCPROFILER", "HSA_TOOLS_", "ROCTX", "ROCTRACER", "RPD_"};
+  for (const char* p : prefixes)
+    if (std::strncmp(kv, p, std::strlen(p)) == 0) return true;
+  return false;
+}
+int run_tool(const std::vector<std::string>& argv, const std::string& log_path, std::string& err) {
+  std::vector<char*> av;
+  for (const std::string& a : argv) av.push_back(const_cast<char*>(a.c_str()));
+  av.push_back(nullptr);
+  std::vector<char*> ev;
+  for (char** e = environ; e && *e; ++e)
+    if (!tool_variable(*e)) ev.push_back(*e);
+  ev.push_back(nullptr);
+  posix_spawn_file_actions_t fa;
+  posix_spawn_file_actions_init(&fa);
+  posix_spawn_file_actions_addopen(&fa, 1, log_path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  posix_spawn_file_actions_adddup2(&fa, 1, 2);
+  posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+  pid_t pid = 0;
+  const int rc = posix_spawn(&pid, av[0], &fa, nullptr, av.data(), ev.data());
+  posix_spawn_file_actions_destroy(&fa);
+  if (rc != 0) { err = std::string("cannot start ") + av[0] + ": " + std::strerror(rc); return -1; }
+  int status = 0;
+  while (waitpid(pid, &status, 0) < 0) {
+    if (errno != EINTR) { err = std::string("waitpid: ") + std::strerror(errno); return -1; }
+  }
+  if (WIFEXITED(status)) return WEXITSTATUS(status);
+  err = "terminated by signal " + std::to_string(WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+  return -1;
+}
+// names the kernel sources a module is compiled from (FNV-1a over the headers, in name order): part of every
+// launch-wisdom key of the module (include/neptune_hip.h "launch wisdom"), so choices measured against other kernels
+// are never reused
+std::string kernel_build_id(const std::string& root) {
+  namespace fs = std::filesystem;
+  std::vector<std::string> files;
+  std::error_code ec;
+  for (const char* sub : {"/neptune-pde-solver_amd/csrc/kernels", "/neptune-pde-solver_amd/csrc/runtime"})
+    for (fs::directory_iterator it(root + sub, ec), end; !ec && it != end; it.increment(ec))
+      if (it->path().extension() == ".hpp") files.push_back(it->path().string());
+  files.push_back(root + "/include/neptune_hip.h");
+  std::sort(files.begin(), files.end());
+  unsigned long long h = 1469598103934665603ull;
+  for (const std::string& f : files) {
+    std::ifstream in(f, std::ios::binary);
+    char buf[65536];
+    while (in.read(buf, sizeof buf) || in.gcount() > 0)
+      for (std::streamsize i = 0; i < in.gcount(); ++i) { h ^= (unsigned char)buf[i]; h *= 1099511628211ull; }
+  }
+  char out[32];
+  std::snprintf(out, sizeof out, "%016llx", h);
+  return out;
 }
 bool front(const char* text, Module& m, Diag& d) {
   if (!text) { d.fail(0, "null module text"); return false; }
@@ -134,15 +205,20 @@ int neptune_lowering_compile(const char* mlir_text, const char* so_path, const c
   // -ffp-contract=off: bodies must evaluate op by op like the reference's FMA-free lowering.
   // NEPTUNE_HIP_FULL_VARIANTS=1 compiles every march tile into the module (longer build; for NEPTUNE_HIP_TUNE=1).
   const char* fullv = std::getenv("NEPTUNE_HIP_FULL_VARIANTS");
-  const std::string defs = (fullv && *fullv && *fullv != '0') ? " -DNEPTUNE_HIP_FULL_VARIANTS=1" : "";
-  const std::string cmd = cc + " --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared" + defs + " -x hip '" + hip_path +
-                          "' -I'" + root + "' -L'" + libdir + "' -lneptune_hip -Wl,-rpath,'" + libdir + "' -o '" + so_path +
-                          "' > '" + log + "' 2>&1";
-  rc = std::system(cmd.c_str());
+  std::vector<std::string> argv = {cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"};
+  if (fullv && *fullv && *fullv != '0') argv.push_back("-DNEPTUNE_HIP_FULL_VARIANTS=1");
+  argv.push_back("-DNEPTUNE_HIP_BUILD_ID=\"" + kernel_build_id(root) + "\"");
+  for (const std::string& a : {std::string("-x"), std::string("hip"), hip_path, "-I" + root, "-L" + libdir, std::string("-lneptune_hip"),
+                               "-Wl,-rpath," + libdir, std::string("-o"), std::string(so_path)})
+    argv.push_back(a);
+  std::string why;
+  rc = run_tool(argv, log, why);
   if (rc != 0) {
     std::ifstream f(log);
     std::stringstream ss;
-    ss << "hipcc failed (" << cmd << "):\n" << f.rdbuf();
+    ss << "hipcc failed (";
+    for (size_t i = 0; i < argv.size(); ++i) ss << (i ? " " : "") << argv[i];
+    ss << ")" << (why.empty() ? "" : ": " + why) << ":\n" << f.rdbuf();
     if (diag_out) *diag_out = dup(ss.str());
     return -2;
   }

@@ -921,6 +921,15 @@ struct Emitter {
     return true;
   }
 
+  // FNV-1a of the emitted constants and body functors: two modules with the same bodies share their measured launches
+  static std::string module_id(const std::string& text) {
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned char c : text) { h ^= c; h *= 1099511628211ull; }
+    char buf[32];
+    snprintf(buf, sizeof buf, "%016llx", h);
+    return buf;
+  }
+
   bool run(std::string& out) {
     // callees before callers: opdefs are emitted in module order, forward declarations cover the rest
     std::ostringstream fwd;
@@ -939,6 +948,8 @@ struct Emitter {
     o << "// Generated by the NeptuneIR HIP lowering (neptune-opt --neptuneir-to-hip).  Do not edit.\n"
       << "// Compile: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared <this file> \\\n"
       << "//          -I<repo> -L<repo>/neptune-pde-solver_amd/lib -lneptune_hip\n"
+      << "// identifies this module's body functors in the launch-wisdom keys (include/neptune_hip.h)\n"
+      << "#define NEPTUNE_HIP_MODULE_ID \"m" << module_id(consts.str() + bodies.str()) << "\"\n"
       << "#include \"neptune-pde-solver_amd/csrc/runtime/lowered_runtime.hpp\"\n"
       << "#include \"neptune-pde-solver_amd/csrc/kernels/body_ops.hpp\"\n\n"
       << "namespace nl = neptune_hip::lowered;\n\nnamespace {\n\n"

@@ -17,9 +17,8 @@
 
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
-#include "../kernels/apply_march2.hpp"
 #include "../kernels/util_kernels.hpp"
-#include "builtin_bodies.hpp"
+#include "rt_bodies.hpp"
 
 using namespace neptune_hip;
 
@@ -57,19 +56,15 @@ void ensure_init() {
 
 inline hipStream_t as_stream(void* p) { return reinterpret_cast<hipStream_t>(p); }
 
-template <class B>
-int apply_body(const neptune_hip_apply_geom_t* g, const void* const* in, void* out, hipStream_t stream,
-               const neptune_hip_launch_cfg_t* cfg) {
-  int rc = geom_check_radius(g, B::radius);
-  if (rc != NEPTUNE_HIP_OK) return rc;
-  return launch_apply<B, typename B::T, B::RANK, B::NIN, typename B::FP>(B{}, g, in, out, stream, cfg);
-}
-template <class B>
-int plan_body(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out,
-              const neptune_hip_launch_cfg_t* cfg) {
-  int rc = geom_check_radius(g, B::radius);
-  if (rc != NEPTUNE_HIP_OK) return rc;
-  return plan_apply<typename B::T, B::RANK, B::NIN, typename B::FP>(g, in, out, cfg);
+// the built-in bodies live in their own translation units (rt_body_*.hip)
+const rtbody::Entry* body_entry(int body) {
+  switch (body) {
+    case NEPTUNE_HIP_BODY_LAP2D5_F64: return &rtbody::lap2d5();
+    case NEPTUNE_HIP_BODY_LAP3D7_F64: return &rtbody::lap3d7();
+    case NEPTUNE_HIP_BODY_LAP3D27_F32: return &rtbody::lap3d27();
+    case NEPTUNE_HIP_BODY_LAP1D3_F64: return &rtbody::lap1d3();
+  }
+  return nullptr;
 }
 
 // out must not overlap an input: every wave reads neighbours other waves may already have
@@ -431,14 +426,7 @@ int neptune_hip_apply_builtin(int body, const neptune_hip_apply_geom_t* g, const
   rc = check_no_alias(g, in, out, body_elem_size(body));
   if (rc != NEPTUNE_HIP_OK) return rc;
   ensure_init();
-  hipStream_t s = as_stream(stream);
-  switch (body) {
-    case NEPTUNE_HIP_BODY_LAP2D5_F64: return apply_body<builtin::Lap2D5>(g, in, out, s, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D7_F64: return apply_body<builtin::Lap3D7>(g, in, out, s, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D27_F32: return apply_body<builtin::Lap3D27>(g, in, out, s, cfg);
-    case NEPTUNE_HIP_BODY_LAP1D3_F64: return apply_body<builtin::Lap1D3>(g, in, out, s, cfg);
-  }
-  return NEPTUNE_HIP_EINVAL;
+  return body_entry(body)->apply(g, in, out, as_stream(stream), cfg);
 }
 
 // two or three chained applies of a built-in body in one pass over HBM (csrc/kernels/apply_march2.hpp)
@@ -453,16 +441,9 @@ int neptune_hip_apply_chain_builtin(int body, int applies, const neptune_hip_app
   rc = check_no_alias(g, in, out, body_elem_size(body));
   if (rc != NEPTUNE_HIP_OK) return rc;
   ensure_init();
-  hipStream_t s = as_stream(stream);
-  switch (body) {
-    case NEPTUNE_HIP_BODY_LAP3D7_F64:
-      return applies == 2 ? launch_apply_twice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg)
-                          : launch_apply_thrice<builtin::Lap3D7, double, 3, 1, builtin::Lap3D7::FP>(builtin::Lap3D7{}, g, in, out, s, cfg);
-    case NEPTUNE_HIP_BODY_LAP2D5_F64:
-      return applies == 2 ? launch_apply_twice<builtin::Lap2D5, double, 2, 1, builtin::Lap2D5::FP>(builtin::Lap2D5{}, g, in, out, s, cfg)
-                          : launch_apply_thrice<builtin::Lap2D5, double, 2, 1, builtin::Lap2D5::FP>(builtin::Lap2D5{}, g, in, out, s, cfg);
-    default: return NEPTUNE_HIP_EUNSUPPORTED;   // 1-D and box bodies: one launch per apply
-  }
+  const rtbody::Entry* e = body_entry(body);
+  if (!e->chain) return NEPTUNE_HIP_EUNSUPPORTED;   // 1-D and box bodies: one launch per apply
+  return e->chain(applies, g, in, out, as_stream(stream), cfg);
 }
 int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                                void* stream, const neptune_hip_launch_cfg_t* cfg) {
@@ -638,24 +619,14 @@ int neptune_hip_step_loop_chain(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn
 int neptune_hip_apply_builtin_plan(int body, const neptune_hip_apply_geom_t* g, const void* const* in,
                                    const void* out, const neptune_hip_launch_cfg_t* cfg) {
   if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
-  switch (body) {
-    case NEPTUNE_HIP_BODY_LAP2D5_F64: return plan_body<builtin::Lap2D5>(g, in, out, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D7_F64: return plan_body<builtin::Lap3D7>(g, in, out, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D27_F32: return plan_body<builtin::Lap3D27>(g, in, out, cfg);
-    case NEPTUNE_HIP_BODY_LAP1D3_F64: return plan_body<builtin::Lap1D3>(g, in, out, cfg);
-  }
-  return NEPTUNE_HIP_EINVAL;
+  const rtbody::Entry* e = body_entry(body);
+  return e ? e->plan(g, in, out, cfg) : NEPTUNE_HIP_EINVAL;
 }
 
 int neptune_hip_apply_builtin_variant(int body, const neptune_hip_apply_geom_t* g, const neptune_hip_launch_cfg_t* cfg) {
   if (!g) return NEPTUNE_HIP_EINVAL;
-  switch (body) {
-    case NEPTUNE_HIP_BODY_LAP2D5_F64: return pick_march_variant<double, 2, builtin::Lap2D5::FP>(g, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D7_F64: return pick_march_variant<double, 3, builtin::Lap3D7::FP>(g, cfg);
-    case NEPTUNE_HIP_BODY_LAP3D27_F32: return pick_march_variant<float, 3, builtin::Lap3D27::FP>(g, cfg);
-    case NEPTUNE_HIP_BODY_LAP1D3_F64: return pick_march_variant<double, 1, builtin::Lap1D3::FP>(g, cfg);
-  }
-  return NEPTUNE_HIP_EINVAL;
+  const rtbody::Entry* e = body_entry(body);
+  return e ? e->variant(g, cfg) : NEPTUNE_HIP_EINVAL;
 }
 
 const char* neptune_hip_kernel_name(int kernel) {

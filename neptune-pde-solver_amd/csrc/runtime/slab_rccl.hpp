@@ -1,5 +1,6 @@
-// slab_rccl.hpp -- the multi-GPU face of one neptune_ir.apply, in C: dim-0 slab halo exchange over RCCL
-// (ncclSend / ncclRecv grouped on a communication stream) overlapped with the interior update.
+// slab_rccl.hpp -- the multi-GPU face of one neptune_ir.apply, in C: dim-0 slab halo exchange overlapped with the
+// interior update.  Two transports behind one communicator type: RCCL (ncclSend / ncclRecv grouped on a communication
+// stream) and peer copies (slab_peer.hpp: hipMemcpyAsync into the neighbour's mapped ghost planes, no CU moves data).
 //
 // The reference has no domain decomposition (every PETSc object lives on PETSC_COMM_SELF,
 // lib/Runtime/PETSc/NeptunePETScRuntime.cpp:136,244,257); SURVEY.md 8(e) defines this path: rank g owns planes
@@ -17,8 +18,10 @@
 #include <string.h>
 
 #include <mutex>
+#include <sched.h>
 
 #include "../../../include/neptune_hip.h"
+#include "slab_peer.hpp"
 
 namespace neptune_hip {
 namespace slab {
@@ -68,7 +71,9 @@ inline RcclApi* rccl() {
 }
 
 struct Comm {
-  ncclComm_t comm = nullptr;
+  int transport = NEPTUNE_HIP_TRANSPORT_RCCL;
+  ncclComm_t comm = nullptr;        // RCCL transport
+  peer::State* peer = nullptr;      // peer-copy transport
   int rank = 0, world = 1;
   char error[320] = "";   // last failure, for neptune_hip_slab_last_error
 };
@@ -96,33 +101,133 @@ inline void set_error(Comm* c, const char* what, const char* detail) {
     }                                                                   \
   } while (0)
 
-// ghost planes of ONE dense local buffer [r_lo ghost | n_own owned | r_hi ghost] x plane_bytes, in place
-inline int exchange(Comm* c, void* field, size_t plane_bytes, int64_t n_own, int r_lo, int r_hi, int peer_lo,
-                    int peer_hi, hipStream_t stream) {
-  if (!c || !field || n_own <= 0 || r_lo < 0 || r_hi < 0) return NEPTUNE_HIP_EINVAL;
+// ---- peer-copy transport: the two handshake kernels are defined in slab_rccl.hip ---------------------------------
+// store `v_lo` / `v_hi` to the (non-null) signal words, then wait until the (non-null) wait words reach the same values
+void peer_signal_wait(hipStream_t stream, uint64_t* sig_lo, uint64_t* sig_hi, const uint64_t* wait_lo, const uint64_t* wait_hi,
+                      uint64_t v_lo, uint64_t v_hi, uint32_t* err, uint32_t code);
+
+inline int peer_exchange_many(Comm* c, void* const* fields, const size_t* plane_bytes, int nfields, int64_t n_own, int r_lo, int r_hi,
+                              int peer_lo, int peer_hi, hipStream_t stream) {
+  peer::State* s = c->peer;
+  auto fail = [&](const char* what, const char* detail) { set_error(c, what, detail); return NEPTUNE_HIP_ECOMM; };
+  if (*s->err_host) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "a device-side wait of an earlier exchange timed out (code %u: %s); the ghost planes since then are stale",
+             *s->err_host, (*s->err_host & 1) ? "neighbour never freed its ghost planes" : "neighbour's planes never arrived");
+    return fail("peer transport", msg);
+  }
+  const int peers[2] = {peer_lo, peer_hi}, r[2] = {r_lo, r_hi};
+  peer::RankShm& me = s->shm->ranks[s->rank];
+  uint64_t n[2] = {0, 0};
+  // 1. publish where my ghost planes are, per side and field (field f of exchange n uses ring entry (n + f) -- a call
+  //    with several fields takes one exchange number per field so that both sides count alike)
+  for (int side = 0; side < 2; ++side) {
+    if (r[side] == 0) continue;
+    for (int f = 0; f < nfields; ++f) {
+      const uint64_t seq = s->seq[side] + 1 + (uint64_t)f;
+      char* base = static_cast<char*>(fields[f]);
+      char* ghost = side == peer::LO ? base : base + (size_t)(r_lo + n_own) * plane_bytes[f];
+      uint32_t w = 0;
+      uint64_t off = 0;
+      // the whole local buffer must lie in one allocation; registering it by its first byte covers both ghost runs
+      if (peer::window_of(s, base, (size_t)(r_lo + n_own + r_hi) * plane_bytes[f], &w, &off) != 0) return fail("peer transport", s->error);
+      peer::Target& t = me.target[side][seq % peer::kRing];
+      t.window = w;
+      t.offset = off + (uint64_t)(ghost - base);
+      t.bytes = (uint64_t)r[side] * plane_bytes[f];
+      t.seq.store(seq, std::memory_order_release);
+    }
+    n[side] = s->seq[side] + (uint64_t)nfields;
+  }
+  // 2. K1: my ghost planes are free for these pushes (all earlier work on `stream` is complete); wait for the neighbours' word
+  peer::Shm* d = s->dshm;
+  auto mail = [&](int rank_) -> peer::RankShm* { return &d->ranks[rank_]; };
+  uint64_t* sig_free[2] = {nullptr, nullptr};
+  uint64_t* sig_arrived[2] = {nullptr, nullptr};
+  const uint64_t* wait_free[2] = {nullptr, nullptr};
+  const uint64_t* wait_arrived[2] = {nullptr, nullptr};
+  for (int side = 0; side < 2; ++side) {
+    if (r[side] == 0) continue;
+    const int opp = 1 - side;
+    sig_free[side] = &mail(peers[side])->peer_free[opp];      // I am the neighbour's `opp`-side neighbour
+    sig_arrived[side] = &mail(peers[side])->arrived[opp];
+    wait_free[side] = &mail(s->rank)->peer_free[side];
+    wait_arrived[side] = &mail(s->rank)->arrived[side];
+  }
+  peer_signal_wait(stream, sig_free[0], sig_free[1], wait_free[0], wait_free[1], n[0], n[1], s->err_dev, 1);
+  // 3. the pushes: my edge planes -> the neighbour's ghost planes (its descriptor exists once it has called this exchange)
+  for (int side = 0; side < 2; ++side) {
+    if (r[side] == 0) continue;
+    const int opp = 1 - side;
+    peer::RankShm& nb = s->shm->ranks[peers[side]];
+    for (int f = 0; f < nfields; ++f) {
+      const uint64_t seq = s->seq[side] + 1 + (uint64_t)f;
+      peer::Target& t = nb.target[opp][seq % peer::kRing];
+      const double t0 = peer::now_s();
+      while (t.seq.load(std::memory_order_acquire) != seq) {
+        if (t.seq.load(std::memory_order_acquire) > seq) return fail("peer transport", "neighbour is ahead by more than the descriptor ring (ranks disagree on the number of exchanges)");
+        if (peer::now_s() - t0 > peer::timeout_s()) {
+          char msg[160];
+          snprintf(msg, sizeof msg, "rank %d never reached exchange %llu on its %s side (it is at %llu)", peers[side], (unsigned long long)seq,
+                   opp == peer::LO ? "lower" : "upper", (unsigned long long)t.seq.load());
+          return fail("peer transport", msg);
+        }
+        sched_yield();
+      }
+      const size_t bytes = (size_t)r[side] * plane_bytes[f];
+      if (t.bytes != bytes) return fail("peer transport", "neighbours disagree on the size of a halo");
+      char* remote = peer::map_window(s, peers[side], t.window);
+      if (!remote) return fail("peer transport", s->error);
+      char* base = static_cast<char*>(fields[f]);
+      char* own = base + (size_t)r_lo * plane_bytes[f];
+      const char* src = side == peer::LO ? own : own + (size_t)(n_own - r_hi) * plane_bytes[f];
+      NEPTUNE_HIP_TRY(c, hipMemcpyAsync(remote + t.offset, src, bytes, hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  // 4. K2: tell the neighbours their planes have landed; wait for mine
+  peer_signal_wait(stream, sig_arrived[0], sig_arrived[1], wait_arrived[0], wait_arrived[1], n[0], n[1], s->err_dev, 2);
+  for (int side = 0; side < 2; ++side)
+    if (r[side] > 0) s->seq[side] = n[side];
+  return NEPTUNE_HIP_OK;
+}
+
+// ghost planes of `nfields` dense local buffers [r_lo ghost | n_own owned | r_hi ghost] x plane_bytes[f], in place
+inline int exchange_many(Comm* c, void* const* fields, const size_t* plane_bytes, int nfields, int64_t n_own, int r_lo, int r_hi,
+                         int peer_lo, int peer_hi, hipStream_t stream) {
+  if (!c || !fields || nfields < 1 || n_own <= 0 || r_lo < 0 || r_hi < 0) return NEPTUNE_HIP_EINVAL;
+  for (int f = 0; f < nfields; ++f)
+    if (!fields[f]) return NEPTUNE_HIP_EINVAL;
   if ((r_lo > 0 && (peer_lo < 0 || peer_lo >= c->world)) || (r_hi > 0 && (peer_hi < 0 || peer_hi >= c->world)))
     return NEPTUNE_HIP_EINVAL;
   if (r_lo > n_own || r_hi > n_own) return NEPTUNE_HIP_EINVAL;  // a halo deeper than the slab would need two hops
   if (r_lo == 0 && r_hi == 0) return NEPTUNE_HIP_OK;
+  if (c->transport == NEPTUNE_HIP_TRANSPORT_PEER)
+    return peer_exchange_many(c, fields, plane_bytes, nfields, n_own, r_lo, r_hi, peer_lo, peer_hi, stream);
   RcclApi* api = rccl();
   if (!api) { set_error(c, "rccl", rccl() ? "" : "library not available"); return NEPTUNE_HIP_ECOMM; }
-  char* base = static_cast<char*>(field);
-  char* own = base + (size_t)r_lo * plane_bytes;
   NEPTUNE_RCCL_TRY(c, api, api->GroupStart());
-  // the neighbour below needs my first r_lo owned planes as ITS upper ghosts, and sends its last ones for my lower
-  // ghosts; symmetric radius on both sides of a cut (both ranks run the same stencil)
-  if (r_lo > 0) {
-    NEPTUNE_RCCL_TRY(c, api, api->Send(own, (size_t)r_lo * plane_bytes, ncclUint8, peer_lo, c->comm, stream));
-    NEPTUNE_RCCL_TRY(c, api, api->Recv(base, (size_t)r_lo * plane_bytes, ncclUint8, peer_lo, c->comm, stream));
-  }
-  if (r_hi > 0) {
-    char* last = own + (size_t)(n_own - r_hi) * plane_bytes;
-    NEPTUNE_RCCL_TRY(c, api, api->Send(last, (size_t)r_hi * plane_bytes, ncclUint8, peer_hi, c->comm, stream));
-    NEPTUNE_RCCL_TRY(c, api, api->Recv(own + (size_t)n_own * plane_bytes, (size_t)r_hi * plane_bytes, ncclUint8, peer_hi,
-                                       c->comm, stream));
+  for (int f = 0; f < nfields; ++f) {
+    char* base = static_cast<char*>(fields[f]);
+    char* own = base + (size_t)r_lo * plane_bytes[f];
+    // the neighbour below needs my first r_lo owned planes as ITS upper ghosts, and sends its last ones for my lower
+    // ghosts; symmetric radius on both sides of a cut (both ranks run the same stencil)
+    if (r_lo > 0) {
+      NEPTUNE_RCCL_TRY(c, api, api->Send(own, (size_t)r_lo * plane_bytes[f], ncclUint8, peer_lo, c->comm, stream));
+      NEPTUNE_RCCL_TRY(c, api, api->Recv(base, (size_t)r_lo * plane_bytes[f], ncclUint8, peer_lo, c->comm, stream));
+    }
+    if (r_hi > 0) {
+      char* last = own + (size_t)(n_own - r_hi) * plane_bytes[f];
+      NEPTUNE_RCCL_TRY(c, api, api->Send(last, (size_t)r_hi * plane_bytes[f], ncclUint8, peer_hi, c->comm, stream));
+      NEPTUNE_RCCL_TRY(c, api, api->Recv(own + (size_t)n_own * plane_bytes[f], (size_t)r_hi * plane_bytes[f], ncclUint8, peer_hi,
+                                         c->comm, stream));
+    }
   }
   NEPTUNE_RCCL_TRY(c, api, api->GroupEnd());
   return NEPTUNE_HIP_OK;
+}
+inline int exchange(Comm* c, void* field, size_t plane_bytes, int64_t n_own, int r_lo, int r_hi, int peer_lo,
+                    int peer_hi, hipStream_t stream) {
+  return exchange_many(c, &field, &plane_bytes, 1, n_own, r_lo, r_hi, peer_lo, peer_hi, stream);
 }
 
 // One sharded apply: everything decided once, a step is then a fixed sequence of stream operations.
@@ -139,8 +244,14 @@ struct Plan {
   neptune_hip_apply_geom_t whole{}, interior{}, edges[2]{};
   neptune_hip_launch_cfg_t cfg{0, -1, 0, 0};
   bool has_cfg = false;
-  hipStream_t comm_stream = nullptr;
+  hipStream_t comm_stream = nullptr;   // created with the greatest priority: the exchange is dispatched ahead of the CU-filling interior grid
   hipEvent_t ready = nullptr, halo_done = nullptr;
+  // optional per-step timing (neptune_hip_slab_plan_timing): a ring of timed events, read back without a sync per step
+  static constexpr int kTimingRing = 64;
+  struct StepEvents { hipEvent_t x0, x1, i0, i1, e1; };
+  bool timing = false;
+  int64_t timed_steps = 0;
+  StepEvents* tev = nullptr;           // kTimingRing sets, created when timing is first switched on
 };
 
 }  // namespace slab

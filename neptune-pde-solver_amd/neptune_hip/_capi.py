@@ -21,6 +21,7 @@ MAX_INPUTS = 4
 
 OK, EINVAL, EUNSUPPORTED, EOOB, ECOMM = 0, -1, -2, -3, -4
 SLAB_ID_BYTES = 128
+TRANSPORT_RCCL, TRANSPORT_PEER = 0, 1
 F64, F32 = 0, 1
 KERNEL_AUTO, KERNEL_DIRECT, KERNEL_MARCH = 0, 1, 2
 FLAG_DIRECT_FLAT = 1   # direct kernel: flat one-lane-per-cell form instead of the rows form
@@ -126,6 +127,12 @@ SIGNATURES = {
     "neptune_hip_autotune_builtin": (_i, [_i, _geom_p, _vpp, _vp, _vp, _i, _cfg_p, C.POINTER(C.c_double)]),
     "neptune_hip_time_apply_fn": (_dbl, [_vp, _geom_p, _vpp, _vp, _vp, _cfg_p, _i, _i]),
     "neptune_hip_autotune_fn": (_i, [_vp, _i, _geom_p, _vpp, _vp, _vp, _i, _cfg_p, C.POINTER(C.c_double)]),
+    "neptune_hip_wisdom_lookup": (_i, [C.c_char_p, _cfg_p]),
+    "neptune_hip_wisdom_store": (_i, [C.c_char_p, _cfg_p, _dbl]),
+    "neptune_hip_wisdom_path": (C.c_char_p, []),
+    "neptune_hip_tune_stats": (None, [_i64p]),
+    "neptune_hip_note_launch": (None, [_i, _i, _i]),
+    "neptune_hip_last_launch": (_i, [_cfg_p]),
     "neptune_hip_time_copy": (_dbl, [_vp, _vp, _sz, _vp, _i, _i, _i]),
     "neptune_hip_copy_mode_count": (_i, []),
     "neptune_hip_event_create": (_vp, []),
@@ -143,6 +150,13 @@ SIGNATURES = {
     "neptune_hip_slab_plan_create": (_vp, [_vp, _vp, _i, _i, _geom_p, _i, _i, _i, _i, _i, _cfg_p]),
     "neptune_hip_slab_apply": (_i, [_vp, _vpp, _vp, _vp, _i]),
     "neptune_hip_slab_plan_destroy": (None, [_vp]),
+    "neptune_hip_slab_unique_id_ex": (_i, [_i, _vp]),
+    "neptune_hip_slab_comm_create_ex": (_vp, [_i, _vp, _i, _i]),
+    "neptune_hip_slab_comm_transport": (C.c_char_p, [_vp]),
+    "neptune_hip_slab_comm_status": (_i, [_vp]),
+    "neptune_hip_halo_exchange_many": (_i, [_vp, _vpp, C.POINTER(C.c_size_t), _i, _i64, _i, _i, _i, _i, _vp]),
+    "neptune_hip_slab_plan_timing": (_i, [_vp, _i]),
+    "neptune_hip_slab_plan_timing_read": (_i, [_vp, C.POINTER(C.c_double)]),
 }
 
 _lib = None

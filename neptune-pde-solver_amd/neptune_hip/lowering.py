@@ -85,8 +85,10 @@ _build_id = None
 def build_id() -> str:
     """identifies everything besides the module text that a compiled module bakes in: the emitter
     (libneptune_lowering.so), the header-only kernels and runtime it is compiled against, the public ABI header,
-    and the runtime library it links (size + mtime: its ABI -- geometry struct, pool, tile numbering -- moves with
-    every rebuild).  A cached shared object built against any other state is never loaded."""
+    and the runtime library it links (its contents: the ABI -- geometry struct, pool, tile numbering -- moves with
+    the sources, not with the file's time stamp, so a `make` that rebuilds the same library or a copy of the tree onto
+    another machine keeps the cache and the stored launch choices valid).  A cached shared object built against any
+    other state is never loaded."""
     global _build_id
     if _build_id is None:
         h = hashlib.sha256()
@@ -99,8 +101,13 @@ def build_id() -> str:
             h.update(f.read_bytes())
         rt = _capi.library_path()
         if rt.exists():
-            st = rt.stat()
-            h.update(f"{rt.name}:{st.st_size}:{st.st_mtime_ns}".encode())
+            h.update(rt.name.encode())
+            with open(rt, "rb") as f:
+                while True:
+                    block = f.read(1 << 22)
+                    if not block:
+                        break
+                    h.update(block)
         _build_id = h.hexdigest()[:16]
     return _build_id
 
@@ -116,9 +123,11 @@ def module_hash(text: str) -> str:
 
 
 def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: bool = True,
-                   cache_directory: Optional[os.PathLike] = None) -> "LoweredModule":
+                   cache_directory: Optional[os.PathLike] = None, load: bool = True) -> Optional["LoweredModule"]:
     """lower + hipcc (gfx950) + load.  Compiling needs no GPU; loading needs libneptune_hip.so.  Without an explicit
-    so_path the object lives in `cache_directory` (default: cache_dir()) under its module_hash."""
+    so_path the object lives in `cache_directory` (default: cache_dir()) under its module_hash.  load=False only fills
+    the cache (what the profiling scripts do before they start rocprofv3: hipcc is started with an environment scrubbed
+    of LD_PRELOAD / ROCP* / HSA_TOOLS_*, csrc/lowering/capi.cpp, but a profiled run should be a pure cache hit)."""
     lib = _load()
     if so_path is None:
         directory = Path(cache_directory) if cache_directory else cache_dir()
@@ -133,6 +142,8 @@ def compile_module(text: str, so_path: Optional[os.PathLike] = None, use_cache: 
         if rc != 0:
             raise LoweringError(_take(lib, diag))
         rep_path.write_text(_take(lib, rep))
+    if not load:
+        return None
     return LoweredModule(so_path, json.loads(rep_path.read_text()))
 
 

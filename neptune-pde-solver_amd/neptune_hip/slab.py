@@ -164,28 +164,41 @@ def exchange_halos(slab: Slab, t: torch.Tensor, group=None, ops: Optional[List[d
     return dist.batch_isend_irecv(ops)
 
 
-class RcclComm:
-    """The C-ABI communicator of include/neptune_hip.h section 8: libneptune_hip.so itself issues the grouped
-    ncclSend / ncclRecv of a halo exchange (no Python, no torch.distributed in the step).  One per process;
-    collective to create.  `peer_lo` / `peer_hi` default to rank -/+ 1."""
+class SlabComm:
+    """The C-ABI communicator of include/neptune_hip.h section 8: libneptune_hip.so itself moves the halo planes (no
+    Python, no torch.distributed in the step).  transport = "rccl": grouped ncclSend / ncclRecv; "peer": every rank
+    pushes its edge planes into its neighbour's ghost planes with peer copies (hipIpc mappings, SDMA over xGMI, no CU
+    moves data; the ranks of one node, and the one transport two processes on ONE device can use).  One per process;
+    collective to create.  `peer_lo` / `peer_hi` default to rank -/+ 1.
 
-    def __init__(self, rank: int, world: int, unique_id: Optional[bytes] = None):
+    Both transports issue work on a stream of their own: synchronise the compute stream (or wait for the step) before
+    issuing torch.distributed collectives on the same device -- two communicators progressing concurrently can deadlock."""
+
+    TRANSPORTS = {"rccl": 0, "peer": 1}
+
+    def __init__(self, rank: int, world: int, unique_id: Optional[bytes] = None, transport: str = "rccl"):
         import ctypes as C
         from . import _capi
         self._capi, self._C = _capi, C
         self.lib = _capi.load()
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.transport = rank, world, transport
         buf = C.create_string_buffer(unique_id, _capi.SLAB_ID_BYTES) if unique_id is not None else None
-        self.ptr = self.lib.neptune_hip_slab_comm_create(buf, rank, world)
+        self.ptr = self.lib.neptune_hip_slab_comm_create_ex(self.TRANSPORTS[transport], buf, rank, world)
         if not self.ptr:
-            raise RuntimeError("neptune_hip_slab_comm_create: " + self.last_error())
+            raise RuntimeError(f"neptune_hip_slab_comm_create_ex({transport}): " + self.last_error())
+
+    def status(self) -> None:
+        """raises once a device-side wait of the peer transport has timed out (a neighbour died or fell behind by more
+        than NEPTUNE_HIP_PEER_TIMEOUT_S): every exchange since then left stale ghost planes"""
+        if self.lib.neptune_hip_slab_comm_status(self.ptr) != 0:
+            raise RuntimeError("neptune_hip_slab_comm_status: " + self.last_error())
 
     def last_error(self) -> str:
         return (self.lib.neptune_hip_slab_last_error() or b"").decode()
 
     @classmethod
-    def from_process_group(cls, group=None, device: Optional[torch.device] = None) -> "RcclComm":
-        """rank 0 draws the RCCL unique id and broadcasts it over the torch.distributed group (any backend);
+    def from_process_group(cls, group=None, device: Optional[torch.device] = None, transport: str = "rccl") -> "SlabComm":
+        """rank 0 draws the unique id and broadcasts it over the torch.distributed group (any backend);
         every rank then joins the communicator on its current device"""
         from . import _capi
         import ctypes as C
@@ -194,7 +207,7 @@ class RcclComm:
         idbuf = C.create_string_buffer(_capi.SLAB_ID_BYTES)
         ok = 1
         if rank == 0:
-            ok = 1 if lib.neptune_hip_slab_unique_id(idbuf) == 0 else 0
+            ok = 1 if lib.neptune_hip_slab_unique_id_ex(cls.TRANSPORTS[transport], idbuf) == 0 else 0
         dev = device if device is not None else (torch.device("cuda") if dist.get_backend(group) == "nccl" else torch.device("cpu"))
         t = torch.tensor(list(idbuf.raw) + [ok], dtype=torch.uint8, device=dev)
         if world > 1:
@@ -202,7 +215,7 @@ class RcclComm:
         raw = bytes(t.cpu().tolist())
         if raw[-1] != 1:
             raise RuntimeError("neptune_hip_slab_unique_id failed on rank 0: " + (lib.neptune_hip_slab_last_error() or b"").decode())
-        return cls(rank, world, raw[:-1])
+        return cls(rank, world, raw[:-1], transport)
 
     def exchange(self, slab: "Slab", t: torch.Tensor, stream: Optional[int] = None,
                  peer_lo: Optional[int] = None, peer_hi: Optional[int] = None) -> None:
@@ -221,6 +234,9 @@ class RcclComm:
         if getattr(self, "ptr", None):
             self.lib.neptune_hip_slab_comm_destroy(self.ptr)
             self.ptr = None
+
+
+RcclComm = SlabComm   # the name of the round-2 API
 
 
 class ShardedApply:
@@ -249,7 +265,7 @@ class ShardedApply:
         self.overlap = overlap
         self.interior, self.edges = slab.regions()
         self.compute = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream()
+        self.comm = torch.cuda.Stream(priority=-1)   # dispatched ahead of the CU-filling interior launch
         self.ready = torch.cuda.Event()
         self.halo_done = torch.cuda.Event()
         self._cache = {}
@@ -312,6 +328,23 @@ class ShardedApply:
                 lib.neptune_hip_slab_plan_destroy(plan)
         except Exception:   # interpreter shutdown
             pass
+
+    def timing(self, on: bool) -> None:
+        """C-ABI transport only: make the following steps record where their time goes (neptune_hip_slab_plan_timing)"""
+        lib = self._apply._capi.load()
+        for plan in self._plans.values():
+            lib.neptune_hip_slab_plan_timing(plan, 1 if on else 0)
+
+    def read_timing(self) -> Optional[dict]:
+        """averages over the steps since timing(True): exchange / interior / edge wait / edges / step, milliseconds"""
+        import ctypes as C
+        lib = self._apply._capi.load()
+        for plan in self._plans.values():
+            out = (C.c_double * 6)()
+            if lib.neptune_hip_slab_plan_timing_read(plan, out) == 0 and out[5] > 0:
+                return {"exchange_ms": out[0], "interior_ms": out[1], "edge_wait_ms": out[2], "edges_ms": out[3],
+                        "step_ms": out[4], "steps": int(out[5])}
+        return None
 
     def __call__(self, fin, fout) -> None:
         slab = self.slab
@@ -385,7 +418,7 @@ class ShardedModule:
         self.peers = peers if peers is not None else (slab.rank - 1, slab.rank + 1)
         self._lib = _capi.load()
         self._comm_stream = None    # created at the first overlapped call (needs a device)
-        self._ready = self._halo_done = None
+        self._ready = self._halo_done = self._ready0 = None
 
     def local_empty(self, dtype=torch.float64, device="cuda") -> torch.Tensor:
         return torch.empty(self.slab.local_shape, dtype=dtype, device=device)
@@ -399,14 +432,19 @@ class ShardedModule:
         if staged or not self.overlap or not all(t.is_cuda for t in tensors):
             return False
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream()
+            self._comm_stream = torch.cuda.Stream(priority=-1)
             self._ready, self._halo_done = lib.neptune_hip_event_create(), lib.neptune_hip_event_create()
+            self._ready0 = lib.neptune_hip_event_create()
         cur = int(torch.cuda.current_stream().cuda_stream)
         comm = int(self._comm_stream.cuda_stream)
         lib.neptune_hip_event_record(self._ready, cur)          # the inputs are complete on the caller's stream
         lib.neptune_hip_stream_wait_event(comm, self._ready)
         if cur != 0:
             lib.neptune_hip_stream_wait_event(None, self._ready)   # lowered functions launch on the null stream
+            # ... and an earlier (asynchronous) call's kernels may still be writing planes there: the exchange must not
+            # send or overwrite them before they are done (torch streams are non-blocking: no implicit ordering)
+            lib.neptune_hip_event_record(self._ready0, None)
+            lib.neptune_hip_stream_wait_event(comm, self._ready0)
         if self.rccl is not None:
             for t in tensors:
                 self.rccl.exchange(self.slab, t, stream=comm, peer_lo=self.peers[0], peer_hi=self.peers[1])

@@ -114,3 +114,26 @@ def c_oracle_entry(kind, u: np.ndarray, variant="entry", lb=None, ub=None) -> np
 
 def load_kats():
     return json.loads((GOLDEN_DIR / "kat_reference_smoke.json").read_text())
+
+
+def prefetch_modules(texts, workers=None):
+    """compile (lower + hipcc) a batch of module texts into the current module cache with a pool of host threads, so
+    that the tests that follow load them as cache hits: hipcc takes 3-10 s per module on one core and the GPU box has
+    16 of them.  The lowering is called through ctypes (the GIL is released for the whole compile); nothing is loaded,
+    nothing touches the GPU.  A text that fails to compile is left to its test to report."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from neptune_hip import lowering
+    texts = list(dict.fromkeys(texts))
+    if not texts:
+        return
+    if workers is None:
+        workers = max(1, min(12, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1) - 2))
+
+    def one(text):
+        try:
+            lowering.compile_module(text, load=False)
+        except Exception:       # noqa: BLE001 - the test that needs this module shows the diagnostic
+            pass
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        list(pool.map(one, texts))

@@ -184,10 +184,14 @@ def env(built_libs, tmp_path_factory):
     assert torch.cuda.is_available()
     os.environ["NEPTUNE_CACHE_DIR"] = str(tmp_path_factory.mktemp("neptune_cache_fuzz"))
     from neptune_hip import lowering
+    helpers.prefetch_modules([gen_module(seed)[0] for seed in SEEDS])   # every seed's module, compiled side by side
     return lowering, torch
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 703, 709, 722, 725, 730, 739, 757])
+SEEDS = [101, 202, 303, 404, 505, 606, 703, 709, 722, 725, 730, 739, 757]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_applies_match_the_oracle(env, monkeypatch, seed):
     lowering, torch = env
     text, shape, elem, ops = gen_module(seed)

@@ -473,6 +473,68 @@ print("TUNE_OK")
     assert p.returncode == 0 and "TUNE_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
+def test_launch_wisdom_is_measured_once_and_reused_by_the_next_process(env, tmp_path):
+    """include/neptune_hip.h "launch wisdom": without any environment switch, the first launch of a large enough apply
+    measures its tiles once and appends the choice to the wisdom file; a SECOND PROCESS finds it there and launches the
+    same configuration without timing anything (tune_stats: 0 measured, hits > 0).  A lowered module and a built-in
+    body; NEPTUNE_HIP_TUNE_MIN_CELLS lowered so that a small field counts as large.  Bits stay exact."""
+    script = tmp_path / "wisdom.py"
+    script.write_text(f"""
+import ctypes as C, json, os, sys
+sys.path.insert(0, {str(helpers.REPO / 'neptune-pde-solver_amd')!r}); sys.path.insert(0, {str(helpers.REPO / 'tests')!r})
+os.environ["NEPTUNE_CACHE_DIR"] = {str(tmp_path)!r}
+os.environ["NEPTUNE_HIP_TUNE_MIN_CELLS"] = "50000"
+os.environ.pop("NEPTUNE_HIP_TUNE", None); os.environ.pop("NEPTUNE_HIP_WISDOM", None)
+import numpy as np, torch, helpers
+from helpers import oracle, bits_equal
+from neptune_hip import lowering, _capi, apply, fields
+lib = _capi.load()
+shape = (24, 20, 256)
+text = helpers.stencil_module("3d7", list(shape))
+mod = lowering.compile_module(text)
+u = helpers.hash_field(shape, np.float64, seed=33)
+want = np.zeros_like(u)
+oracle.Module.parse(text).call("entry", want, u)
+d_in = torch.from_numpy(u).cuda()
+last = []
+for rep in range(3):
+    d_out = torch.zeros(shape, dtype=torch.float64, device="cuda")
+    mod.call("entry", d_out, d_in)
+    assert bits_equal(d_out.cpu().numpy(), want)
+    cfg = _capi.LaunchCfg()
+    assert lib.neptune_hip_last_launch(C.byref(cfg)) == 1
+    last.append((cfg.kernel, cfg.variant, cfg.chunk))
+assert last[0] == last[1] == last[2] and last[0][0] == _capi.KERNEL_MARCH and last[0][2] > 0, last
+a = fields.DeviceField.hashed(shape, _capi.F64, seed=2)
+b = fields.DeviceField.empty_like(a); c = fields.DeviceField.empty_like(a)
+bounds = ([1, 1, 1], [n - 1 for n in shape])
+apply.apply_builtin(_capi.BODY_LAP3D7_F64, [a], b, bounds)
+cfg = _capi.LaunchCfg(); lib.neptune_hip_last_launch(C.byref(cfg))
+apply.apply_builtin(_capi.BODY_LAP3D7_F64, [a], c, bounds, cfg=apply.make_cfg(_capi.KERNEL_DIRECT))
+torch.cuda.synchronize()
+assert apply.count_mismatch(b, c) == 0
+# a small field is left alone: the fixed automatic tile, nothing measured
+small = fields.DeviceField.hashed((8, 8, 128), _capi.F64, seed=3)
+apply.apply_builtin(_capi.BODY_LAP3D7_F64, [small], fields.DeviceField.empty_like(small), ([1, 1, 1], [7, 7, 127]))
+stats = (C.c_int64 * 3)()
+lib.neptune_hip_tune_stats(stats)
+print("WISDOM", json.dumps({{"measured": stats[0], "hits": stats[1], "stored": stats[2], "module": last[0],
+                             "builtin": (cfg.kernel, cfg.variant, cfg.chunk), "path": lib.neptune_hip_wisdom_path().decode()}}))
+""")
+    import json
+    runs = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "WISDOM" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+        runs.append(json.loads(p.stdout.split("WISDOM", 1)[1].strip().splitlines()[0]))
+    first, second = runs
+    assert first["path"] == str(tmp_path / "wisdom_v1.txt") and (tmp_path / "wisdom_v1.txt").exists()
+    assert first["measured"] == 2 and first["stored"] == 2 and first["hits"] == 0, first      # the module's apply and the built-in body
+    assert second["measured"] == 0 and second["stored"] == 0 and second["hits"] == 2, second  # nothing timed: both found in the file
+    assert second["module"] == first["module"] and second["builtin"] == first["builtin"]
+    assert len((tmp_path / "wisdom_v1.txt").read_text().splitlines()) == 2
+
+
 def test_async_mode_keeps_results_and_order(env, tmp_path):
     """NEPTUNE_HIP_ASYNC=1: device-resident calls return without synchronising; chained steps (pooled temporaries reused
     while earlier kernels may still run), a device result and a scalar result still come out right"""

@@ -160,7 +160,18 @@ def env(built_libs, tmp_path_factory):
     assert torch.cuda.is_available()
     os.environ["NEPTUNE_CACHE_DIR"] = str(tmp_path_factory.mktemp("neptune_cache_mh"))
     from neptune_hip import lowering
+    helpers.prefetch_modules([case_text(name)[0] for name in CASES])   # every case's module, compiled side by side
     return lowering, torch
+
+
+def case_text(name):
+    shape, elem, nin, accesses, margin, kernel = CASES[name]
+    rank = len(shape)
+    lb = [margin] * rank
+    ub = [n - margin for n in shape]
+    if rank == 3:
+        lb[0], ub[1] = margin + 1, shape[1] - margin - 2      # bounds tighter than the halo margin: more copy-through
+    return module_text(shape, elem, nin, accesses, lb, ub), lb, ub
 
 
 @pytest.fixture
@@ -180,11 +191,7 @@ def test_several_halo_inputs_match_the_oracle(env, launch_env, name):
     shape, elem, nin, accesses, margin, kernel = CASES[name]
     rank = len(shape)
     dt = np.float64 if elem == "f64" else np.float32
-    lb = [margin] * rank
-    ub = [n - margin for n in shape]
-    if rank == 3:
-        lb[0], ub[1] = margin + 1, shape[1] - margin - 2      # bounds tighter than the halo margin: more copy-through
-    text = module_text(shape, elem, nin, accesses, lb, ub)
+    text, lb, ub = case_text(name)
     ins = [helpers.hash_field(shape, dt, seed=40 + k) for k in range(nin)]
     want = np.full(shape, -7.0, dtype=dt)
     oracle.Module.parse(text).call("entry", want, *ins)

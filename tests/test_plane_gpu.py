@@ -23,10 +23,15 @@ def env(built_libs, tmp_path_factory):
     assert torch.cuda.is_available()
     os.environ["NEPTUNE_CACHE_DIR"] = str(tmp_path_factory.mktemp("neptune_cache_plane"))
     from neptune_hip import lowering
+    import soak_plane
+    helpers.prefetch_modules([soak_plane.gen_case(seed)[0] for seed in SEEDS])   # compiled side by side
     return lowering, torch
 
 
-@pytest.mark.parametrize("seed", [3, 14, 40, 1007, 1009, 1012, 1016, 3004, 3019])
+SEEDS = [3, 14, 40, 1007, 1009, 1012, 1016, 3004, 3019]
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_plane_footprints_match_the_oracle(env, seed):
     import soak_plane
     lowering, torch = env

@@ -1,9 +1,11 @@
-"""include/neptune_hip.h section 8 on ONE GPU: the C-ABI halo exchange and sharded apply executed for real --
-an RCCL communicator of world size 1 whose neighbours are the rank itself (loop-back), so ncclSend / ncclRecv, the
-communication stream, the events and the exchange-beside-interior schedule all run.  With in-order matching of the
-two send/receive pairs the loop-back fills the lower ghost planes with the rank's own FIRST owned planes and the
-upper ones with its LAST owned planes; the oracle is run on exactly that array.  (Two ranks cannot share one GPU under
-RCCL; the world-2/3 geometry is covered by the gloo tests, tests/test_slab_gloo.py and tests/test_slab_gpu.py.)"""
+"""include/neptune_hip.h section 8 on ONE GPU: the C-ABI halo exchange and sharded apply executed for real, on both
+transports -- a communicator of world size 1 whose neighbours are the rank itself (loop-back), so ncclSend / ncclRecv
+(or the peer transport's handshake kernels and pushes), the communication stream, the events and the
+exchange-beside-interior schedule all run.  RCCL matches the two send/receive pairs in order, so its loop-back fills
+the lower ghost planes with the rank's own FIRST owned planes and the upper ones with its LAST; the peer transport
+pushes to the neighbour's opposite side, a periodic wrap: lower ghosts = LAST owned planes.  The oracle is run on
+exactly the array each implies.  (Two ranks cannot share one GPU under RCCL; they can on the peer transport:
+tests/test_slab_peer_gpu.py runs the C path with two and three processes.)"""
 import ctypes as C
 
 import numpy as np
@@ -15,7 +17,22 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def nh():
+def cache_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("neptune_cache_slab_c")   # modules compile once for both transports
+
+
+def loopback(local, lo, hi, r, transport):
+    """the local buffer after a loop-back exchange of its r ghost planes per side"""
+    ext = local.copy()
+    if transport == "rccl":
+        ext[:lo], ext[hi:] = local[lo:lo + r], local[hi - r:hi]
+    else:
+        ext[:lo], ext[hi:] = local[hi - r:hi], local[lo:lo + r]
+    return ext
+
+
+@pytest.fixture(scope="module", params=["rccl", "peer"])
+def nh(request):
     import torch
     from neptune_hip import _capi, apply, fields, slab
 
@@ -26,8 +43,11 @@ def nh():
     ns.lib = _capi.load()
     ns.lib.neptune_hip_init(0)
     torch.cuda.set_device(0)
-    ns.comm = slab.RcclComm(0, 1)          # world of one rank: no unique id needed
+    ns.transport = request.param
+    ns.comm = slab.SlabComm(0, 1, transport=request.param)          # world of one rank: no unique id needed
+    assert ns.lib.neptune_hip_slab_comm_transport(ns.comm.ptr).decode() == request.param
     yield ns
+    ns.comm.status()                       # no device-side wait of the peer transport ever timed out
     ns.comm.close()
 
 
@@ -51,10 +71,17 @@ def test_halo_exchange_loopback_fills_the_ghost_planes(nh, radius):
     nh.comm.exchange(sl, t, peer_lo=0, peer_hi=0)
     nh.torch.cuda.synchronize()
     got = t.cpu().numpy()
-    want = u.copy()
-    want[:lo] = u[lo:lo + radius]            # my first owned planes came back as the lower ghosts
-    want[hi:] = u[hi - radius:hi]            # my last owned planes as the upper ghosts
+    want = loopback(u, lo, hi, radius, nh.transport)
     assert helpers.bits_equal(got, want), helpers.mismatch_report(got, want)
+    # several buffers in one grouped exchange / one handshake
+    ts = [nh.torch.from_numpy(helpers.hash_field(sl.local_shape, np.float64, seed=32 + k)).cuda() for k in range(3)]
+    before = [t.cpu().numpy() for t in ts]
+    ptrs = (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    pb = (C.c_size_t * 3)(*[ts[0][0].numel() * 8] * 3)
+    assert nh.lib.neptune_hip_halo_exchange_many(nh.comm.ptr, ptrs, pb, 3, sl.n_own, radius, radius, 0, 0, None) == 0
+    nh.torch.cuda.synchronize()
+    for t, b in zip(ts, before):
+        assert helpers.bits_equal(t.cpu().numpy(), loopback(b, lo, hi, radius, nh.transport))
 
 
 def test_halo_exchange_rejects_bad_requests(nh):
@@ -90,20 +117,27 @@ def test_sharded_apply_through_the_c_plan_matches_the_oracle(nh, kind, shape_own
     nh.torch.cuda.synchronize()
     got = fout.numpy()[lo:hi]
     # the oracle on the array the loop-back exchange produces, with the slab's logical origin
-    ext = local.copy()
-    ext[:lo] = local[lo:lo + 1]
-    ext[hi:] = local[hi - 1:hi]
+    ext = loopback(local, lo, hi, 1, nh.transport)
     lb, ub = sl.clip_bounds(gbounds)
     want = helpers.oracle_entry(kind, ext, origin=list(sl.local_lb), bounds=(lb, ub))[lo:hi]
     assert helpers.bits_equal(got, want), helpers.mismatch_report(got, want)
     # the input's ghost planes now hold the exchanged data, the owned planes are untouched
     assert helpers.bits_equal(fin.numpy(), ext)
+    # where a step's time goes (neptune_hip_slab_plan_timing): five timed events per step, read back afterwards
+    op.timing(True)
+    for _ in range(3):
+        op(fin, fout)
+    t = op.read_timing()
+    assert t is not None and t["steps"] == 3 and t["step_ms"] > 0 and t["exchange_ms"] > 0 and t["edge_wait_ms"] >= 0
+    assert t["interior_ms"] <= t["step_ms"] * 1.01
+    op.timing(False)
+    assert helpers.bits_equal(fout.numpy()[lo:hi], want)
 
 
-def test_sharded_apply_of_a_lowered_module_through_the_c_plan(nh, tmp_path, monkeypatch):
+def test_sharded_apply_of_a_lowered_module_through_the_c_plan(nh, cache_dir, monkeypatch):
     """a user stencil (the committed 13-point fixture: radius 2 along dim 0, two ghost planes per side) through its
     geometry-level entry"""
-    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(cache_dir))
     from neptune_hip import lowering
     text = (helpers.FIXTURE_DIR / "apply-3d-13pt.mlir").read_text()
     gshape = (20, 18, 256)
@@ -122,9 +156,7 @@ def test_sharded_apply_of_a_lowered_module_through_the_c_plan(nh, tmp_path, monk
     op(fin, fout)
     nh.torch.cuda.synchronize()
     # oracle: the global field whose planes [3, 16) are the local buffer after the loop-back exchange
-    ext = local.copy()
-    ext[:lo] = local[lo:lo + 2]
-    ext[hi:] = local[hi - 2:hi]
+    ext = loopback(local, lo, hi, 2, nh.transport)
     glob = np.zeros(gshape)
     glob[sl.local_lb[0]:sl.local_ub[0]] = ext
     want = helpers.oracle.Module.parse(text).call("lap13", glob)[sl.start:sl.stop]
@@ -150,11 +182,11 @@ def test_plan_without_neighbours_is_a_plain_apply(nh):
 
 
 @pytest.mark.parametrize("symbol,overlap", [("entry", True), ("step", True), ("entry", False)])
-def test_sharded_module_exchange_beside_the_interior(nh, tmp_path, monkeypatch, symbol, overlap):
+def test_sharded_module_exchange_beside_the_interior(nh, cache_dir, monkeypatch, symbol, overlap):
     """whole lowered functions on a slab with the exchange left in flight (neptune_hip_set_slab_pending): the
     function's stencil apply does its interior, waits for the halo event, then the planes next to the ghosts.  Loop-back
     RCCL on one GPU; the oracle runs the same function on the global field that the exchange implies."""
-    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(cache_dir))
     from neptune_hip import lowering
     gshape = (26, 10, 256)
     text = helpers.stencil_module("3d7", list(gshape), time_step=0.125)
@@ -170,9 +202,7 @@ def test_sharded_module_exchange_beside_the_interior(nh, tmp_path, monkeypatch, 
     assert sm.call(symbol, lb, la) is lb
     nh.torch.cuda.synchronize()
     assert nh.lib.neptune_hip_get_slab_pending() is None            # consumed by the call, slab view cleared
-    ext = local.copy()
-    ext[:lo] = local[lo:lo + 1]
-    ext[hi:] = local[hi - 1:hi]
+    ext = loopback(local, lo, hi, 1, nh.transport)
     glob = np.zeros(gshape)
     glob[sl.local_lb[0]:sl.local_ub[0]] = ext
     out = np.zeros(gshape)

@@ -7,6 +7,8 @@ TAG=${1:?tag}; CTRS=${2:?counters}; shift 2 || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmcm_$TAG
 mkdir -p "$OUT"
+# fill the module cache OUTSIDE the profiler: the profiled run must not start hipcc (exec hops under the preloaded tool)
+python3 "$ROOT/tools/time_module.py" "$@" --compile-only
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/raw" -- python3 "$ROOT/tools/time_module.py" "$@" > "$OUT/time.json" 2> "$OUT/err.txt" || { tail -20 "$OUT/err.txt"; exit 1; }
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"

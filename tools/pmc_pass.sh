@@ -6,6 +6,8 @@ TAG=${1:?tag}; CTRS=${2:?counters}; shift 2 || true
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
+# fill the module cache OUTSIDE the profiler: the profiled run must not start hipcc
+python3 "$ROOT/bench.py" "$@" --compile-only
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d "$OUT/raw" -- python3 "$ROOT/bench.py" "$@" > "$OUT/bench.json" 2> "$OUT/err.txt" || { tail -20 "$OUT/err.txt"; exit 1; }
 python3 - "$OUT" <<'PY' | tee "$OUT/summary.txt"

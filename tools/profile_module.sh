@@ -6,6 +6,8 @@ TAG=${1:?tag}; MLIR=${2:?mlir}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# fill the module cache OUTSIDE the profiler
+python3 "$ROOT/tools/time_module.py" "$MLIR" --compile-only
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw" -- python3 "$ROOT/tools/time_module.py" "$MLIR" --reps 50 > "$OUT/time.json" 2> "$OUT/err.txt" || { tail -20 "$OUT/err.txt"; exit 1; }
 cp "$(find "$OUT/raw" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv"

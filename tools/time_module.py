@@ -17,10 +17,16 @@ def main():
     ap.add_argument("mlir")
     ap.add_argument("--symbol", default="entry")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--compile-only", action="store_true",
+                    help="fill the module cache and exit without touching the GPU (run this BEFORE profiling: a cache miss "
+                         "inside a rocprofv3 --pmc run would start hipcc from a profiled process)")
     args = ap.parse_args()
-    import torch
     from neptune_hip import lowering
     text = Path(args.mlir).read_text()
+    if args.compile_only:
+        lowering.compile_module(text, load=False)
+        return
+    import torch
     mod = lowering.compile_module(text)
     sig = mod.signatures[args.symbol]
     m = re.search(r"#b\s*=\s*#neptune_ir.bounds<lb = \[([^\]]*)\], ub = \[([^\]]*)\]>", text)
