@@ -158,12 +158,17 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
     lib_path = REPO / "oracle" / "_build" / "liboracle.so"
     if not lib_path.exists():
         return None
-    # the fused leg runs one OpenMP thread per CPU this process may use: say so explicitly instead of leaving it to the
-    # OpenMP runtime's default (which read 128 of 256 usable CPUs on the round-2 boxes); set before the library loads
+    # the fused leg runs one OpenMP thread per CPU this process may use, set explicitly: the OpenMP runtime is already
+    # loaded (torch brings one) and keeps the default it read then -- 128 threads on boxes whose affinity mask holds
+    # 256 CPUs (an OMP_NUM_THREADS of the box's environment, or its cgroup's CPU share)
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    os.environ["OMP_NUM_THREADS"] = str(usable)
-    os.environ.setdefault("OMP_PROC_BIND", "false")
+    env_threads = os.environ.get("OMP_NUM_THREADS")
     lib = C.CDLL(str(lib_path))
+    lib.ref_num_threads.restype = C.c_int
+    default_threads = int(lib.ref_num_threads())
+    lib.ref_set_num_threads.argtypes = [C.c_int]
+    lib.ref_set_num_threads.restype = None
+    lib.ref_set_num_threads(usable)
     nd = len(shape)
     ct = C.c_double if elem_bytes == 8 else C.c_float
     dt = np.float64 if elem_bytes == 8 else np.float32
@@ -202,7 +207,6 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
             assert rc == 0
             best = dtm if best is None else min(best, dtm)
         res[variant] = (updates / best, best)
-    lib.ref_num_threads.restype = C.c_int
     threads = int(lib.ref_num_threads())
     dims = "x".join(str(n) for n in sshape)
     return {
@@ -210,8 +214,9 @@ def cpu_baseline(body_name, shape, elem_bytes, sample_planes):
         "sample": f"{dims} slab of the workload (same plane size), faithful restatement of the reference "
                   f"lowering: malloc + copy-through + scalar loop nest + store copy, best of 3 runs, {res['entry'][1]:.2f} s each",
         "fused_all_cores": {"value": res["fused"][0], "cores": threads, "seconds": res["fused"][1],
-                            "cores_note": f"OMP_NUM_THREADS set to the {usable} CPUs in this process's affinity mask; the OpenMP "
-                                          f"runtime reports {threads} threads"},
+                            "cores_note": f"one OpenMP thread per CPU of this process's affinity mask ({usable}), set with "
+                                          f"omp_set_num_threads; the runtime's own default was {default_threads} "
+                                          f"(OMP_NUM_THREADS in the environment: {env_threads!r})"},
         "host_cores": os.cpu_count(),
         "host_cores_usable": usable,
     }
@@ -245,6 +250,16 @@ def main():
     sys.stdout.flush()
     os.dup2(2, 1)
     dog = Watchdog(rank)
+    # the modules of the other configurations compile on host threads while this process imports torch, builds the
+    # headline module and tunes it (hipcc runs as a child process; the ctypes call releases the GIL); joined before the
+    # clock ramp so that nothing competes with the timed region
+    precompile = None
+    if extra:
+        from concurrent.futures import ThreadPoolExecutor
+        from neptune_hip import lowering as _lw
+        _pool = ThreadPoolExecutor(max_workers=len(EXTRA_CONFIGS))
+        precompile = [_pool.submit(_lw.compile_module, fixture_text(WORKLOADS[n][0], WORKLOADS[n][1]), None, True, None, False)
+                      for n in EXTRA_CONFIGS]
     dog.stage("import torch", 600)
     import torch
     import torch.distributed as dist
@@ -515,6 +530,10 @@ def main():
     # restored every 10 ramp steps as well: launches on overflowed inf/NaN data draw less power and run ~7 %
     # faster than on real data (kernel trace of the 27-point workload: 181 us against 197 us), which would make
     # the ramp unrepresentative and skew a profiler's per-kernel average.
+    if precompile is not None:
+        dog.stage("hipcc of the other configurations' modules", 900)
+        for f in precompile:
+            f.result()
     dog.stage("clock ramp", 300)
     t_ramp = time.perf_counter()
     n_ramp = 0
@@ -741,6 +760,9 @@ def verify_against_oracle(args, torch, dist, world, rank, sl, bufs, refill, step
         first = sl.start + (1 if sl.r_lo else 0)
         if chunk and first + c < sl.stop:
             want_planes |= {first + c - 1, first + c}
+    if args.emulate_rank:     # a loop-back exchange fills the ghosts with this rank's own planes: the planes next to a cut are not the global result
+        want_planes -= {sl.start} if sl.r_lo else set()
+        want_planes -= {sl.stop - 1} if sl.r_hi else set()
     planes = sorted(p for p in want_planes if sl.start <= p < sl.stop)
     row_shape = tuple(gshape[1:])
     bad = []

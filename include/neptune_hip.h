@@ -257,14 +257,19 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
 
 /* Several steps per pass over HBM.  neptune_hip_apply_chain_builtin computes out = A(A(in)) (applies = 2) or A(A(A(in)))
  * (applies = 3) for built-in body A in ONE launch -- the intermediate fields exist in registers only; the same operations on
- * the same operands as separate launches, hence the same bits -- when the body is a rank-3 single-input radius-1 star and the
- * geometry qualifies (all boxes equal, rows a whole number of 64-byte granules, launch region restricted along dim 0 only);
- * otherwise NEPTUNE_HIP_EUNSUPPORTED and nothing is launched.  neptune_hip_apply2_builtin is the applies = 2 form.  Lowered
- * applies export the same as <function>_<k>__geom2 / __geom3.
- * neptune_hip_step_loop uses them for the built-in bodies on its own; neptune_hip_step_loop_chain is the same loop with a
- * lowered apply's pair / triple entries `fn2`, `fn3` (NULL = none) next to its single-step entry `fn`
- * (neptune_hip_step_loop_pairs: fn3 = NULL).  The newest state ends in fields[steps % 2] whatever the grouping.  The
- * reference steps one apply per pass on the host (runtime forward Euler, NeptunePETScRuntime.cpp:677-712). */
+ * the same operands as separate launches, hence the same bits.  Scope: single-input radius-1 stars of rank 3 (the 7-point
+ * family) and of rank 2 (the 5-point family: neptune_apply_march2_rank2), the fused explicit Euler step of such an operator
+ * included, when the geometry qualifies (all boxes equal, rows a whole number of 64-byte granules, launch region restricted
+ * along dim 0 only); otherwise NEPTUNE_HIP_EUNSUPPORTED and nothing is launched.  neptune_hip_apply2_builtin is the
+ * applies = 2 form.  Lowered applies export the same as <function>_<k>__geom2 / __geom3.
+ * neptune_hip_step_loop uses them for the built-in bodies ON ITS OWN for fields of NEPTUNE_HIP_CHAIN_MIN_CELLS cells
+ * (default 4e6) and more; neptune_hip_step_loop_chain is the same loop with a lowered apply's pair / triple entries `fn2`,
+ * `fn3` (NULL = none) next to its single-step entry `fn` (neptune_hip_step_loop_pairs: fn3 = NULL).  The newest state ends
+ * in fields[steps % 2] whatever the grouping -- and that is the ONLY field defined after the loop: with chained launches the
+ * intermediate states live in registers, so fields[(steps + 1) % 2] does NOT hold state steps - 1 (with one launch per step
+ * it would).  A caller that needs the previous state as well sets NEPTUNE_HIP_NO_PAIRS=1 (one launch per step) or raises
+ * NEPTUNE_HIP_CHAIN_MIN_CELLS.  The reference steps one apply per pass on the host (runtime forward Euler,
+ * NeptunePETScRuntime.cpp:677-712). */
 int neptune_hip_apply_chain_builtin(int body, int applies, const neptune_hip_apply_geom_t *g, const void *const *in,
                                     void *out, void *stream, const neptune_hip_launch_cfg_t *cfg);
 int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t *g, const void *const *in, void *out,

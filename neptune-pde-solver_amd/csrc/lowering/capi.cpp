@@ -57,6 +57,12 @@ std::string report_json(const LowerInfo& info) {
     for (auto& c : why) if (c == '"') c = '\'';
     o << (i ? ", " : "") << "{\"symbol\": \"" << info.skipped[i].first << "\", \"reason\": \"" << why << "\"}";
   }
+  o << "], \"outlined\": [";
+  for (size_t i = 0; i < info.outlined.size(); ++i) {
+    const auto& x = info.outlined[i];
+    o << (i ? ", " : "") << "{\"symbol\": \"" << x.symbol << "\", \"function\": \"" << x.function << "\", \"value\": \"" << x.value
+      << "\", \"line\": " << x.line << "}";
+  }
   o << "], \"applies\": [";
   for (size_t i = 0; i < info.applies.size(); ++i) {
     const ApplyInfo& a = info.applies[i];

@@ -921,6 +921,112 @@ struct Emitter {
     return true;
   }
 
+  // ---- outlining: the stencil part of a function that also holds solver ops ----------------------------------
+  // Every current-style input of the reference has this shape (test/smoke_tests/smoke_time_advance.mlir:53-84: @entry
+  // computes %ustar with a neptune_ir.apply, then hands it to an implicit time_advance).  The solver op stays on the
+  // host (RuntimeLowering, out of scope); what CAN run on the GPU is every value such an op consumes that is computed
+  // by applies / operator calls from the function's own arguments.  Each becomes an exported symbol
+  // <function>__stencil_<k>(<the function's memref arguments>) -> memref, with the expanded-memref ABI like any
+  // lowered function, which the reference's CPU-lowered function can call in place of its scf loop nest.
+  static std::unique_ptr<Op> clone_op(const Op& src) {
+    auto op = std::make_unique<Op>();
+    op->name = src.name; op->results = src.results; op->operands = src.operands; op->attrs = src.attrs; op->types = src.types;
+    op->offsets = src.offsets; op->callee = src.callee; op->literal = src.literal; op->predicate = src.predicate;
+    op->opaque = src.opaque; op->line = src.line;
+    for (auto& r : src.regions) {
+      auto b = std::make_unique<Block>();
+      b->args = r->args;
+      for (auto& o : r->ops) b->ops.push_back(clone_op(*o));
+      op->regions.push_back(std::move(b));
+    }
+    return op;
+  }
+  std::vector<std::unique_ptr<Function>> outlined_funcs;   // keeps the synthetic functions alive
+
+  void outline_stencil_parts(const Function& f, std::vector<const Function*>& todo) {
+    const auto& ops = f.body.ops;
+    std::map<std::string, int> def_at;
+    for (size_t oi = 0; oi < ops.size(); ++oi)
+      for (auto& r : ops[oi]->results) def_at[r] = (int)oi;
+    // tainted: results of solver ops and everything computed from them -- and, from a store of such a value on, the
+    // field it went into (and every alias of that field)
+    std::map<std::string, std::string> root;   // value -> the function argument / value it aliases
+    auto root_of = [&](const std::string& v) { auto it = root.find(v); return it == root.end() ? v : it->second; };
+    std::map<std::string, bool> tainted;
+    std::map<std::string, bool> dirty_root;
+    std::vector<bool> op_tainted(ops.size(), false);
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+      const Op& op = *ops[oi];
+      const std::string& n = op.name;
+      if (n == "neptune_ir.wrap" || n == "neptune_ir.unwrap" || n == "neptune_ir.load" || n == "neptune_ir.as_tensor" || n == "neptune_ir.from_tensor")
+        if (!op.results.empty() && !op.operands.empty()) root[op.results[0]] = root_of(op.operands[0]);
+      bool t = op.opaque;
+      for (auto& v : op.operands) t = t || tainted[v] || dirty_root[root_of(v)];
+      op_tainted[oi] = t;
+      for (auto& r : op.results) tainted[r] = t;
+      if (t && n == "neptune_ir.store" && op.operands.size() >= 2) dirty_root[root_of(op.operands[1])] = true;
+    }
+    // live-outs: untainted temps produced by an apply / operator call / explicit time_advance and consumed by a tainted op
+    std::vector<std::string> live;
+    for (size_t oi = 0; oi < ops.size(); ++oi) {
+      if (!op_tainted[oi]) continue;
+      for (auto& v : ops[oi]->operands) {
+        auto d = def_at.find(v);
+        if (d == def_at.end() || op_tainted[d->second]) continue;
+        const Op& p = *ops[d->second];
+        const bool producer = p.name == "neptune_ir.apply" || !p.callee.empty();
+        if (producer && std::find(live.begin(), live.end(), v) == live.end()) live.push_back(v);
+      }
+    }
+    int k = 0;
+    for (const std::string& v : live) {
+      // backward slice of v over untainted ops
+      std::vector<bool> need(ops.size(), false);
+      std::vector<std::string> work{v};
+      bool ok = true;
+      while (!work.empty()) {
+        const std::string x = work.back();
+        work.pop_back();
+        auto d = def_at.find(x);
+        if (d == def_at.end()) continue;            // a function argument
+        if (op_tainted[d->second]) { ok = false; break; }
+        if (need[d->second]) continue;
+        need[d->second] = true;
+        for (auto& o : ops[d->second]->operands) work.push_back(o);
+      }
+      const int last = def_at[v];
+      // a store before the producer could feed the slice through memory (a load of the stored field): such functions
+      // are left alone rather than outlined with a side effect the caller would see twice
+      for (int oi = 0; ok && oi < last; ++oi)
+        if (ops[oi]->name == "neptune_ir.store") ok = false;
+      if (!ok) continue;
+      const Op& prod = *ops[last];
+      const Type vt = prod.name == "neptune_ir.apply" ? prod.types[prod.operands.size()] : (prod.name == "neptune_ir.time_advance" ? prod.types[0] : prod.types.back());
+      if (!vt.is_tempish()) continue;
+      auto g = std::make_unique<Function>();
+      g->name = f.name + "__stencil_" + std::to_string(k);
+      g->kind = FuncKind::Func;
+      g->arg_types = f.arg_types;
+      g->result_types = {vt};
+      g->line = prod.line;
+      g->body.args = f.body.args;
+      for (size_t oi = 0; oi < ops.size(); ++oi)
+        if (need[oi]) g->body.ops.push_back(clone_op(*ops[oi]));
+      auto ret = std::make_unique<Op>();
+      ret->name = "func.return";
+      ret->operands = {v};
+      ret->types = {vt};
+      ret->line = prod.line;
+      g->body.ops.push_back(std::move(ret));
+      std::string why;
+      if (!lowerable(*g, why)) continue;
+      info.outlined.push_back({g->name, f.name, v, prod.line});
+      todo.push_back(g.get());
+      outlined_funcs.push_back(std::move(g));
+      ++k;
+    }
+  }
+
   // FNV-1a of the emitted constants and body functors: two modules with the same bodies share their measured launches
   static std::string module_id(const std::string& text) {
     unsigned long long h = 1469598103934665603ull;
@@ -936,8 +1042,14 @@ struct Emitter {
     std::vector<const Function*> todo;
     for (auto& f : m.funcs) {
       std::string why;
-      if (!lowerable(*f, why)) { info.skipped.push_back({f->name, why}); continue; }
+      if (!lowerable(*f, why)) {
+        info.skipped.push_back({f->name, why});
+        outline_stencil_parts(*f, todo);    // ... but the stencil values its solver ops consume are (see above)
+        continue;
+      }
       todo.push_back(f.get());
+    }
+    for (auto* f : todo) {
       fwd << "static nl::Val " << f->name << "__impl(nl::Scope& sc";
       for (size_t i = 0; i < f->arg_types.size(); ++i) fwd << ", const nl::Val&";
       fwd << ", const nl::Val* dest, int* ret_arg, double* sret);\n";

@@ -39,6 +39,10 @@ struct LowerInfo {
   std::vector<std::string> lowered;                            // exported symbols
   std::vector<std::pair<std::string, std::string>> skipped;    // (symbol, reason)
   std::vector<ApplyInfo> applies;
+  // stencil parts of functions that are not lowered as a whole (they hold solver ops): each is an exported symbol that
+  // computes one value the solver op consumes, from the function's own arguments
+  struct Outlined { std::string symbol, function, value; int line = 0; };
+  std::vector<Outlined> outlined;
 };
 
 // emit_hip.cpp

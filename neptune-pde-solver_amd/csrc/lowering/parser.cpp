@@ -324,7 +324,9 @@ struct Parser {
     }
     return ok();
   }
-  void skip_opaque() {
+  // skip the text of an op outside the hot-path subset; the SSA values it mentions are kept as its operands, so that
+  // the emitter can tell which stencil results a solver op consumes (emit_hip.cpp: outlining)
+  void skip_opaque(Op* op = nullptr) {
     int depth = 0;
     while (true) {
       const Tok& k = peek();
@@ -341,6 +343,7 @@ struct Parser {
       }
       if (k.kind == Tk::Punct && std::strchr("{([<", k.text[0])) ++depth;
       else if (k.kind == Tk::Punct && std::strchr("})]>", k.text[0])) --depth;
+      if (op && k.kind == Tk::Id && k.text[0] == '%') op->operands.push_back(k.text);
       next();
     }
   }
@@ -513,7 +516,7 @@ struct Parser {
     if (n.compare(0, 11, "neptune_ir.") == 0) {
       // solver / time-stepping surface: outside the stencil hot path (stays on the host path)
       op.opaque = true;
-      skip_opaque();
+      skip_opaque(&op);
       return true;
     }
     diag.fail(op.line, "unsupported operation '" + n + "'");

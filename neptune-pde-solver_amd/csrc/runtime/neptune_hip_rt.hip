@@ -155,7 +155,10 @@ template <bool XPAY>
 int vec_update(int dtype, int64_t n, double a, const void* x, void* y, void* stream) {
   if (!x || !y || n < 0) return NEPTUNE_HIP_EINVAL;
   if (n == 0) return NEPTUNE_HIP_OK;
-  
+  if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
+  // the kernel reads x and writes y through __restrict__ pointers: overlapping ranges would be undefined behaviour
+  if (overlaps(x, (size_t)n * (dtype == NEPTUNE_HIP_F64 ? 8 : 4), y, (size_t)n * (dtype == NEPTUNE_HIP_F64 ? 8 : 4))) return NEPTUNE_HIP_EINVAL;
+  ensure_init();
   const int64_t want = (n + 255) / 256;
   const uint32_t blocks = (uint32_t)(want < 256 * 32 ? want : 256 * 32);
   if (dtype == NEPTUNE_HIP_F64)

@@ -208,6 +208,16 @@ int ref_fused_lap3d27_f32(float *out, const float *in, int64_t n0, int64_t n1, i
   return 0;
 }
 
+/* team size of the fused all-core variants; the OpenMP runtime fixes its default when it is first loaded (an
+ * OMP_NUM_THREADS set later in the process is not seen), so a caller that wants one thread per usable CPU says so here */
+void ref_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 int ref_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

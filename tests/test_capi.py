@@ -181,3 +181,17 @@ def test_module_cache_key_depends_on_the_build(built_libs, monkeypatch):
     assert lowering.module_hash(text) != a
     monkeypatch.setattr(lowering, "_build_id", None)
     assert lowering.module_hash(text) == a and len(lowering.build_id()) == 16
+
+
+def test_vector_updates_reject_overlapping_operands_before_touching_a_device():
+    """neptune_hip_axpy / _xpay read x and write y through __restrict__ pointers: overlapping ranges are refused
+    (NEPTUNE_HIP_EINVAL) by the argument checks, which run before the device is initialised"""
+    import ctypes as C
+    from neptune_hip import _capi
+    lib = _capi.load()
+    buf = (C.c_double * 64)()
+    base = C.addressof(buf)
+    assert lib.neptune_hip_axpy(_capi.F64, 16, 1.0, base, base + 8 * 8, None) == _capi.EINVAL      # [0,16) and [8,24) overlap
+    assert lib.neptune_hip_xpay(_capi.F64, 16, base, 1.0, base, None) == _capi.EINVAL              # x == y
+    assert lib.neptune_hip_axpy(7, 16, 1.0, base, base + 8 * 32, None) == _capi.EINVAL             # unknown element type
+    assert lib.neptune_hip_axpy(_capi.F64, 0, 1.0, base, base, None) == _capi.OK                   # nothing to do

@@ -119,3 +119,36 @@ def test_c_krylov_loop_with_device_pointers_through_the_reference_abi(built_libs
     np.testing.assert_allclose(rs_dev[:10], rs_ref[:10], rtol=1e-9)
     assert np.abs(x_dev - x).max() <= 1e-8 * np.abs(x).max()
     assert np.all(x_dev[0] == 0) and np.all(x_dev[:, :, -1] == 0)
+
+
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_c_caller_in_the_shape_of_the_snes_residual_thunk(built_libs, tmp_path, monkeypatch, mode):
+    """tests/thunk_abi/snes_residual_thunk.c reaches a lowered nonlinear_opdef the way the reference's SNES callback does
+    (NeptunePETScRuntime.cpp:1303-1361: dlsym, the iterate and TWO captures as expanded rank-2 memrefs, a NeptuneMemRef2D
+    back by value, released by the caller): with host arrays and plain free() -- the reference's thunk unchanged -- and
+    with device pointers and neptune_rt_free.  Bit for bit against the oracle (scf.if rim branch included)."""
+    import os
+    import subprocess
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    from neptune_hip import _capi, lowering
+    text = (helpers.REPO / "tests/mlir_tests/nonlinear/residual-2d-2cap.mlir").read_text()
+    mod = lowering.compile_module(text)
+    assert {a["function"]: (a["kernel"], a["inputs"]) for a in mod.report["applies"]}["residual"] == ("march", 3)
+    shape = (48, 256)
+    ins = [helpers.hash_field(shape, np.float64, seed=60 + k) for k in range(3)]
+    want = oracle.Module.parse(text).call("residual", *ins)
+    for k, a in enumerate(ins):
+        (tmp_path / f"in{k}.bin").write_bytes(a.tobytes())
+    exe = tmp_path / "snes_thunk"
+    libdir = _capi.LIB_PATH.parent
+    subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Werror", "-I", str(helpers.REPO / "include"),
+                    str(helpers.REPO / "tests/thunk_abi/snes_residual_thunk.c"), "-L", str(libdir), "-lneptune_hip", "-ldl",
+                    f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    p = subprocess.run([str(exe), str(mod.path), "residual", "48", "256", *[str(tmp_path / f"in{k}.bin") for k in range(3)],
+                        str(tmp_path / "F.bin"), mode], capture_output=True, text=True, env=dict(os.environ), timeout=600)
+    assert p.returncode == 0 and f"SNES_THUNK_OK {mode}" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    got = np.frombuffer((tmp_path / "F.bin").read_bytes(), dtype=np.float64).reshape(shape)
+    assert helpers.bits_equal(got, want), helpers.mismatch_report(got, want)
+    assert helpers.bits_equal(got[0], (ins[0] - ins[1])[0])            # the rim branch: x - up
+    if mode == "device":
+        assert "pool_cached_bytes 0" in p.stdout                       # nothing was staged through a device shadow

@@ -40,6 +40,23 @@ def test_reference_smoke_bodies_known_answers(env):
         assert dev.is_cuda and bits_equal(dev.cpu().numpy(), want), k["name"] + " (device)"
 
 
+def test_outlined_stencil_part_of_a_solver_function_known_answer(env):
+    """tests/golden/kat_outline_1d.mlir: @entry holds an implicit time_advance and is not lowered; the value it hands to
+    the solver op is exported as entry__stencil_0(out, in) -- on the reference driver's input 1..16 that is KAT-2
+    (smoke_time_advance.mlir:59-70), bit for bit, with host buffers and with device buffers"""
+    lowering, torch = env
+    mod = lowering.compile_module((helpers.GOLDEN_DIR / "kat_outline_1d.mlir").read_text())
+    assert "entry" not in mod.symbols and "entry__stencil_0" in mod.symbols
+    kat = [k for k in helpers.load_kats()["kats"] if k["symbol"] == "kat_react"][0]
+    u, want = _vec(kat["inputs"][0]), _vec(kat["expected"])
+    out = np.zeros(16)
+    got = mod.call("entry__stencil_0", out, u)               # host buffers: a fresh malloc'ed result, @entry's arguments untouched
+    assert isinstance(got, np.ndarray) and got is not out and bits_equal(got, want), mismatch_report(got, want)
+    assert not out.any() and bits_equal(u, _vec(kat["inputs"][0]))
+    dev = mod.call("entry__stencil_0", torch.zeros(16, dtype=torch.float64, device="cuda"), torch.from_numpy(u).cuda())
+    assert dev.is_cuda and bits_equal(dev.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("kind,shape", [("2d5", (33, 256)), ("3d7", (12, 10, 128)), ("3d27", (9, 8, 256)), ("3d7", (7, 6, 9))])
 def test_fixture_entry_host_and_device(env, kind, shape):
     lowering, torch = env
