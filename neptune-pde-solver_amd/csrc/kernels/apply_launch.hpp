@@ -7,9 +7,9 @@
 //     its input's box -- the reference performs no check there and reads out of bounds
 //     (lib/Passes/DataflowLowering.cpp:380-410; test/smoke_tests/smoke_apply.mlir:4-9 does);
 //     this backend refuses such a plan instead of emulating undefined behaviour.
-//   * march kernel when: footprint allows it, rank >= 2, all inputs share the result's box,
-//     the contiguous extent is a multiple of the 16-byte lane vector and at least one wave
-//     wide, all base pointers are 16-byte aligned, and the region only restricts dim 0.
+//   * march kernel when: footprint allows it, input 0 shares the result's box and every other input's box CONTAINS it
+//     (staggered grids, fields that carry their ghost layers: MarchParams::view), the contiguous extent is at least one
+//     wave wide, the result and the inputs in the result's box are 16-byte aligned, and the region only restricts dim 0.
 //     A march tile index may stand for the plane-in-LDS kernels (apply_plane.hpp): tile 7 for every footprint they can run,
 //     every index for footprints nothing else holds (3-D stars beyond radius 4, several wide halo inputs, radius-2 boxes).
 //   * otherwise the direct kernel.
@@ -74,6 +74,27 @@ inline bool geom_bounds_empty(const neptune_hip_apply_geom_t* g) {
   for (int d = 0; d < g->rank; ++d)
     if (g->lb[d] >= g->ub[d]) return true;
   return false;
+}
+
+// What an apply's UNCONDITIONAL accesses reach per input and dimension, as the offsets themselves: lo = the most negative
+// offset (<= 0), hi = the most positive (>= 0); hi < lo: the input is not accessed unconditionally.  A staggered-grid body
+// reads a face field at [0] and [+1] only -- its reach is (0, +1), and bounds that start at the face field's lower bound
+// are legal (the symmetric radius form below would refuse them).  The lowering emits one per apply.
+struct Reach {
+  int32_t lo[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK];
+  int32_t hi[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK];
+};
+inline int geom_check_radius(const neptune_hip_apply_geom_t* g, const Reach& reach) {
+  int rc = geom_validate(g);
+  if (rc != NEPTUNE_HIP_OK) return rc;
+  if (geom_bounds_empty(g)) return NEPTUNE_HIP_OK;
+  for (int k = 0; k < g->num_inputs; ++k)
+    for (int d = 0; d < g->rank; ++d) {
+      const int64_t lo = reach.lo[k][d], hi = reach.hi[k][d];
+      if (hi < lo) continue;  // input not accessed at all
+      if (g->lb[d] + lo < g->in_lb[k][d] || g->ub[d] + hi > g->in_ub[k][d]) return NEPTUNE_HIP_EOOB;
+    }
+  return NEPTUNE_HIP_OK;
 }
 
 inline int geom_check_radius(const neptune_hip_apply_geom_t* g,
@@ -410,9 +431,30 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
     ok = ok && plane_bytes < 0x7fffffffLL;
   }
   for (int k = 0; ok && k < NIN; ++k) {
-    for (int d = 0; d < RANK; ++d)
-      ok = ok && g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d];
-    ok = ok && ((uintptr_t)in[k] % 16 == 0);
+    // input 0 is also the copy-through source, read at the result's physical index (DataflowLowering.cpp:283-287): same
+    // box.  Inputs 1.. index through their own lower bounds (:382-410): any box that contains the result's.
+    bool same = true;
+    int64_t kplane = (int64_t)sizeof(T);
+    for (int d = 0; d < RANK; ++d) {
+      same = same && g->in_lb[k][d] == g->out_lb[d] && g->in_ub[k][d] == g->out_ub[d];
+      ok = ok && g->in_lb[k][d] <= g->out_lb[d] && g->in_ub[k][d] >= g->out_ub[d];
+      const int64_t n = g->in_ub[k][d] - g->in_lb[k][d];
+      ok = ok && n < 0x7fffffffLL;
+      if (d > 0 || RANK == 1) kplane *= n;
+    }
+    ok = ok && kplane < 0x7fffffffLL && (k > 0 || same);
+    if (!same) {
+      // cells of this input to the right of the result's rows (a field on the K faces, ghost cells) may be read by the
+      // result's last cells.  At the end of a wave's span they arrive as halo cells (element loads, clamped per cell); in
+      // the middle of one they are the next lane's vector, which must then exist as a whole: the rows end on a span
+      // boundary, or the input has a whole lane vector of cells there -- or none at all.  (The LDS kernels fetch halo cells
+      // at the end of a WINDOW: launch_apply_impl keeps such inputs off windows wider than one span.)
+      const int64_t n2 = g->out_ub[RANK - 1] - g->out_lb[RANK - 1], extra = g->in_ub[k][RANK - 1] - g->out_ub[RANK - 1];
+      ok = ok && (extra == 0 || extra >= VK || n2 % ((int64_t)kWave * VK) == 0);
+    }
+    // rows of an input in the result's box start on 16-byte boundaries with it; a box of its own puts them anywhere (the
+    // loads are then unaligned 16-byte accesses, like ragged rows)
+    ok = ok && ((uintptr_t)in[k] % (same ? 16 : sizeof(T)) == 0);
   }
   ok = ok && ((uintptr_t)out % 16 == 0);
   if constexpr (RANK == 2) {
@@ -588,6 +630,16 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     int variant = pick_march_variant<T, RANK, FP>(g, cfg);
     if (RANK == 3 && variant == 6 && !(cfg && cfg->variant == 6) && march3_variant_scratch<Body, T, RANK, NIN, FP>(6) > 0)
       variant = 4;  // automatic choice only: this body spills on the 8-rows-per-lane tile
+    if constexpr (NIN > 1) {
+      // an input with fewer than a lane vector of cells right of the result's rows relies on the halo cells at the end of a
+      // wave's span (plan_apply); the LDS kernels fetch theirs at the end of a window: keep it on one-span-wide windows
+      const MarchVariant* mv = march_variant(RANK, variant);
+      if (mv && mv->pln && mv->WK > 1)
+        for (int k = 1; k < NIN; ++k) {
+          const int64_t extra = g->in_ub[k][RANK - 1] - g->out_ub[RANK - 1];
+          if (extra > 0 && extra < (int64_t)(16 / sizeof(T))) variant = RANK == 3 ? 7 : 0;   // pln_rj4_wj8_wk1 / tile_rj4_wj8_wk1
+        }
+    }
     // rank-2 tile form: (d0,d1) -> (J,K), one plane (the LDS tile kernel is a tile form whatever the table row says)
     const bool jk = RANK == 2 && (march_variant(RANK, variant)->jk || tile2_only<T, FP, RANK>());
     auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
@@ -612,6 +664,26 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
       P.pub[a] = (int32_t)hi;
     }
     axes(g->out_lb, P.olb, 0);
+    if constexpr (NIN > 1) {
+      // per-input views (MarchParams::view): pitch, shift and the result-physical range each input holds, per kernel axis
+      for (int k = 0; k < NIN; ++k) {
+        int64_t kshape[3], ksh[3], kn[3], s3[3];
+        for (int d = 0; d < RANK; ++d) {
+          kshape[d] = g->in_ub[k][d] - g->in_lb[k][d];
+          ksh[d] = g->out_lb[d] - g->in_lb[k][d];
+        }
+        axes(kshape, kn, 1);
+        axes(ksh, s3, 0);
+        InView& vw = P.view[k];
+        vw.row_b = (int32_t)(kn[2] * (int64_t)sizeof(T));
+        vw.plane_b = kn[1] * kn[2] * (int64_t)sizeof(T);
+        for (int a = 0; a < 3; ++a) {
+          vw.sh[a] = (int32_t)s3[a];
+          vw.lo[a] = (int32_t)-s3[a];
+          vw.hi[a] = (int32_t)(kn[a] - s3[a] - 1);
+        }
+      }
+    }
     P.rJ0 = 0; P.rJ1 = P.N1;
     if (jk) {  // one plane; a launch region restricted along d0 is a row range of it
       P.rI0 = 0; P.rI1 = 1;

@@ -39,11 +39,25 @@
 
 namespace neptune_hip {
 
+// Inputs 1.. may live in boxes of their own (DataflowLowering.cpp:382-410: every input subtracts its OWN lower bound;
+// only input 0 must have the result's shape, :283-287) -- a face-located field of extent N+1 beside a cell-located result,
+// a field that carries its ghost layers.  The fast kernels take such an input when its box CONTAINS the result box: the
+// kernel keeps walking result-physical coordinates (i, j, k) and reads input n at (i, j, k) + sh through the input's own
+// row / plane pitch; coordinates that fall outside what the input holds are clamped into [lo, hi] (such reads only ever
+// feed cells outside apply.bounds, whose body value is discarded -- an in-bounds access was validated by the plan).
+struct InView {
+  int64_t plane_b;        // bytes from one plane of this input to the next
+  int32_t row_b;          // bytes from one row to the next
+  int32_t sh[3];          // (out_lb - in_lb) per kernel axis: result-physical -> input-physical
+  int32_t lo[3], hi[3];   // result-physical coordinates the input holds, inclusive: [-sh, extent - sh - 1]
+};
+
 template <class T, int NIN>
 struct MarchParams {
   const T* in[NIN];
   T* out;
-  int32_t N0, N1, N2;      // extents along (I,J,K); identical for result and all inputs
+  int32_t N0, N1, N2;      // extents along (I,J,K) of the result and of input 0 (other inputs: `view`)
+  InView view[NIN];        // read by the kernels only when NIN > 1 (view[0] is always the identity)
   // Rows need not be a whole number of 16-byte vectors.  Ks: cells [0,Ks) of every row are stored by
   // this kernel (a multiple of VK); Kl: the last vector start that may be loaded (N2 rounded down to
   // VK, minus VK).  Aligned rows: Ks = N2, Kl = N2-VK.  Ragged rows (N2 % VK != 0): Ks = Kl, i.e. the
@@ -59,6 +73,48 @@ struct MarchParams {
   int32_t chunk;           // planes per workgroup
   uint32_t nJ, nK;         // tiles along J and K (tiles along I = gridDim.x / (nJ*nK))
 };
+
+// view-aware addressing shared by the LDS kernels (apply_plane.hpp): row j / cell k / plane ip are result-physical, input n
+// may be a run-time (wave-uniform) index
+template <class T, int NIN>
+__device__ __forceinline__ uint32_t view_row_bytes(const MarchParams<T, NIN>& P, int n, int32_t j) {
+  if (NIN > 1 && n > 0) {
+    const InView& vw = P.view[n];
+    j = j < vw.lo[1] ? vw.lo[1] : (j > vw.hi[1] ? vw.hi[1] : j);
+    return (uint32_t)(j + vw.sh[1]) * (uint32_t)vw.row_b + (uint32_t)vw.sh[2] * (uint32_t)sizeof(T);   // K shift folded in
+  }
+  j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+  return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+}
+template <class T, int NIN>
+__device__ __forceinline__ uint32_t view_cell_bytes(const MarchParams<T, NIN>& P, int n, int32_t k) {
+  if (NIN > 1 && n > 0) {
+    const InView& vw = P.view[n];
+    k = k < vw.lo[2] ? vw.lo[2] : (k > vw.hi[2] ? vw.hi[2] : k);
+  } else {
+    k = k < 0 ? 0 : (k >= P.N2 ? P.N2 - 1 : k);
+  }
+  return (uint32_t)k * (uint32_t)sizeof(T);
+}
+// byte offset within a row of the 16-byte vector that starts at cell k (result-physical), clamped so that the whole vector
+// lies in the row: the result's rows end at Kl + VK, an input in a box of its own may hold more cells to the right
+template <class T, int NIN>
+__device__ __forceinline__ uint32_t view_lane_bytes(const MarchParams<T, NIN>& P, int n, int32_t k) {
+  constexpr int VK = 16 / (int)sizeof(T);
+  int32_t kmax = P.Kl;
+  if (NIN > 1 && n > 0) kmax = P.view[n].hi[2] - VK + 1;
+  return (uint32_t)(k < kmax ? k : kmax) * (uint32_t)sizeof(T);
+}
+template <class T, int NIN>
+__device__ __forceinline__ const char* view_plane_base(const MarchParams<T, NIN>& P, int n, int32_t ip) {
+  if (NIN > 1 && n > 0) {
+    const InView& vw = P.view[n];
+    const int32_t ic = ip < vw.lo[0] ? vw.lo[0] : (ip > vw.hi[0] ? vw.hi[0] : ip);
+    return reinterpret_cast<const char*>(P.in[n]) + (int64_t)(ic + vw.sh[0]) * vw.plane_b;
+  }
+  const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+  return reinterpret_cast<const char*>(P.in[n]) + (int64_t)ic * ((int64_t)P.N1 * P.N2 * (int64_t)sizeof(T));
+}
 
 template <class T> struct Vec16;
 template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); };
@@ -279,6 +335,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   const bool lane_ok = k0 < P.Ks;  // Ks % VK == 0, so a lane is entirely in or out
   const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
   const int32_t kw_end = kw + kWave * VK;
+  // ... per input when there are several: an input in a box of its own may hold whole vectors right of the result's rows
+  uint32_t lane_bv[NIN > 1 ? NIN : 1];
+  static_for<(NIN > 1 ? NIN : 1)>([&](auto nc) { constexpr int n = nc; lane_bv[n] = view_lane_bytes(P, n, k0); });
 
   const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
   const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
@@ -286,24 +345,43 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
 
   // byte offsets of the rows this wave touches (halo rows clamped into the field: a clamped
-  // row is only ever read for cells outside apply.bounds, whose body value is discarded)
-  uint32_t rowb[NR];
-  static_for<NR>([&](auto sc) {
-    constexpr int s = sc;
-    int32_t j = j0 + (s - R1);
-    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
-    rowb[s] = (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+  // row is only ever read for cells outside apply.bounds, whose body value is discarded).  One set for the result and
+  // input 0; with several inputs one set per input (InView: own pitch, own clamp range, K shift folded in).
+  constexpr int NV = NIN > 1 ? NIN : 1;
+  uint32_t rowb[NV][NR];
+  static_for<NV>([&](auto nc) {
+    constexpr int n = nc;
+    static_for<NR>([&](auto sc) {
+      constexpr int s = sc;
+      int32_t j = j0 + (s - R1);
+      if constexpr (NIN > 1 && n > 0) {
+        const InView& vw = P.view[n];
+        j = j < vw.lo[1] ? vw.lo[1] : (j > vw.hi[1] ? vw.hi[1] : j);
+        rowb[n][s] = (uint32_t)(j + vw.sh[1]) * (uint32_t)vw.row_b + (uint32_t)vw.sh[2] * (uint32_t)sizeof(T);
+      } else {
+        j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
+        rowb[n][s] = (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
+      }
+    });
   });
   // byte offsets (within a row) of the cells just outside the wave's span, clamped
-  uint32_t khlb[NS], khrb[NS];
-  static_for<NS>([&](auto xc) {
-    constexpr int x = xc;
-    int32_t kl = kw - R2 + x;
-    kl = kl < 0 ? 0 : (kl >= P.N2 ? P.N2 - 1 : kl);
-    int32_t kr = kw_end + x;
-    kr = kr >= P.N2 ? P.N2 - 1 : kr;
-    khlb[x] = (uint32_t)kl * (uint32_t)sizeof(T);
-    khrb[x] = (uint32_t)kr * (uint32_t)sizeof(T);
+  uint32_t khlb[NV][NS], khrb[NV][NS];
+  static_for<NV>([&](auto nc) {
+    constexpr int n = nc;
+    static_for<NS>([&](auto xc) {
+      constexpr int x = xc;
+      int32_t kl = kw - R2 + x, kr = kw_end + x;
+      if constexpr (NIN > 1 && n > 0) {
+        const InView& vw = P.view[n];
+        kl = kl < vw.lo[2] ? vw.lo[2] : (kl > vw.hi[2] ? vw.hi[2] : kl);
+        kr = kr < vw.lo[2] ? vw.lo[2] : (kr > vw.hi[2] ? vw.hi[2] : kr);
+      } else {
+        kl = kl < 0 ? 0 : (kl >= P.N2 ? P.N2 - 1 : kl);
+        kr = kr >= P.N2 ? P.N2 - 1 : kr;
+      }
+      khlb[n][x] = (uint32_t)kl * (uint32_t)sizeof(T);
+      khrb[n][x] = (uint32_t)kr * (uint32_t)sizeof(T);
+    });
   });
 
   // ---- register state ----
@@ -319,20 +397,30 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // rows whose K halo is needed: own rows always, J-halo rows only for box stencils
   auto need_khalo = [](int s) constexpr { return R2 > 0 && (BOX || (s >= R1 && s < R1 + RJ)); };
 
-  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
-    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
-    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
+  // plane ip (result-physical, clamped into what the input holds) of input n
+  auto plane_base = [&](auto nc, int32_t ip) -> const char* {
+    constexpr int n = decltype(nc)::value;
+    if constexpr (NIN > 1 && n > 0) {
+      const InView& vw = P.view[n];
+      const int32_t ic = ip < vw.lo[0] ? vw.lo[0] : (ip > vw.hi[0] ? vw.hi[0] : ip);
+      return reinterpret_cast<const char*>(P.in[n]) + (int64_t)(ic + vw.sh[0]) * vw.plane_b;
+    } else {
+      const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+      return reinterpret_cast<const char*>(P.in[n]) + (int64_t)ic * plane_b;
+    }
   };
+  constexpr auto vidx = [](int n) constexpr { return NIN > 1 ? n : 0; };   // which row / halo offset set input n uses
   // all_rows = true: fetch the J-halo rows from global memory too (prologue planes, which do
   // not pass through the LDS exchange)
   auto load_rows = [&](auto hc, int32_t ip, V(&rows)[NR], auto all_rows_c) {
     constexpr bool all_rows = decltype(all_rows_c)::value;
     if constexpr (HAS_HALO) {
-      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
+      constexpr int hin = halo_input_of(HMASK, decltype(hc)::value);
+      const char* base = plane_base(std::integral_constant<int, hin>{}, ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
         auto ld = [&] {
-          const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+          const V* src = reinterpret_cast<const V*>(base + (rowb[vidx(hin)][s] + lane_bv[vidx(hin)]));
           if constexpr (NTL) rows[s] = __builtin_nontemporal_load(src);
           else rows[s] = *src;
         };
@@ -353,13 +441,14 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   // the LDS exchange only the workgroup's outermost waves need them from global memory.
   auto load_jhalo = [&](auto hc, int32_t ip, V(&jh)[NJH]) {
     if constexpr (JH_LATE && HAS_HALO) {
-      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
+      constexpr int hin = halo_input_of(HMASK, decltype(hc)::value);
+      const char* base = plane_base(std::integral_constant<int, hin>{}, ip);
       static_for<2 * R1>([&](auto xc) {
         constexpr int x = xc;
         constexpr int s = x < R1 ? x : RJ + x;  // ring slot of that row (R1 + RJ + (x - R1))
         const bool want = !LDSJ || (x < R1 ? wj < halo_dist(x) : wj + halo_dist(x) > WJ - 1);
         if (want) {
-          const V* src = reinterpret_cast<const V*>(base + (rowb[s] + lane_b));
+          const V* src = reinterpret_cast<const V*>(base + (rowb[vidx(hin)][s] + lane_bv[vidx(hin)]));
           if constexpr (NTL) jh[x] = __builtin_nontemporal_load(src);
           else jh[x] = *src;
         }
@@ -368,14 +457,15 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   };
   auto load_khalos = [&](auto hc, int32_t ip, T(&hl)[NR][NS], T(&hr)[NR][NS]) {
     if constexpr (HAS_HALO && R2 > 0) {
-      const char* base = plane_base(P.in[halo_input_of(HMASK, decltype(hc)::value)], ip);
+      constexpr int hin = halo_input_of(HMASK, decltype(hc)::value);
+      const char* base = plane_base(std::integral_constant<int, hin>{}, ip);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
         if constexpr (need_khalo(s)) {
           static_for<R2>([&](auto xc) {
             constexpr int x = xc;
-            hl[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[s] + khlb[x])));
-            hr[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[s] + khrb[x])));
+            hl[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[vidx(hin)][s] + khlb[vidx(hin)][x])));
+            hr[s][x] = scalar_load(reinterpret_cast<const T*>(base + (rowb[vidx(hin)][s] + khrb[vidx(hin)][x])));
           });
         }
       });
@@ -385,10 +475,10 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
       if constexpr (!((HMASK >> n) & 1u)) {
-        const char* base = plane_base(P.in[n], ip);
+        const char* base = plane_base(nc, ip);
         static_for<RJ>([&](auto rc) {
           constexpr int r = rc;
-          dst[n][r] = *reinterpret_cast<const V*>(base + (rowb[r + R1] + lane_b));
+          dst[n][r] = *reinterpret_cast<const V*>(base + (rowb[vidx(n)][r + R1] + lane_bv[vidx(n)]));
         });
       }
     });
@@ -581,8 +671,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
       if (row_ok[r] && lane_ok) {
-        // rowb[r+R1] is this own row's offset (own rows are never clamped when row_ok)
-        V* dst = reinterpret_cast<V*>(obase + (rowb[r + R1] + lane_b));
+        // rowb[0][r+R1] is this own row's offset in the result (own rows are never clamped when row_ok)
+        V* dst = reinterpret_cast<V*>(obase + (rowb[0][r + R1] + lane_b));
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }

@@ -140,37 +140,39 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   if (ib >= ie) return;
   const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
 
-  auto row_bytes = [&](int32_t j) -> uint32_t {
-    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
-    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
-  };
-  uint32_t rowb[RJ];
-  static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[r] = row_bytes(j0 + r); });
+  // own-row offsets: one set for the result and input 0, one per input when there are several (InView, apply_march.hpp)
+  constexpr int NV = NIN > 1 ? NIN : 1;
+  constexpr auto vidx = [](int n) constexpr { return NIN > 1 ? n : 0; };
+  uint32_t rowb[NV][RJ], lane_bv[NV];
+  static_for<NV>([&](auto nc) {
+    constexpr int n = nc;
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[n][r] = view_row_bytes(P, n, j0 + r); });
+    lane_bv[n] = view_lane_bytes(P, n, k0);
+  });
 
   // halo-row units of this wave: unit uu = w + t*NW -> halo input uu / NU, halo row x = (uu % NU) / WK (x < R1: above the
-  // window), wave span (uu % NU) % WK.  All inputs share the result's box, so a unit's offset within a plane does not
-  // depend on its input; only the base pointer does.
+  // window), wave span (uu % NU) % WK.
   uint32_t hsrc[NHWX];      // byte offset within a plane of my 16 bytes of the unit
   int32_t hdst[NHWX];       // LDS cell index (within one buffer) they go to; -1: no unit
-  const T* hfield[NHWX];    // the unit's input
+  int hin[NHWX];            // the unit's input
   static_for<NHW>([&](auto tc) {
     constexpr int tt = tc;
     const int uu = w + tt * NW;
     const int hh = NU ? uu / NU : 0, u = NU ? uu % NU : 0;
     const int x = u / WK, sp = u % WK;
     const int32_t kc = kw0 + sp * SPAN + lane * VK;
-    hsrc[tt] = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1)) + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T);
+    hin[tt] = halo_input_of(HMASK, 0);
+    static_for<NH>([&](auto hc) { constexpr int h = hc; if (hh == h) hin[tt] = halo_input_of(HMASK, h); });
+    hsrc[tt] = view_row_bytes(P, hin[tt], x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1)) + view_lane_bytes(P, hin[tt], kc);
     hdst[tt] = uu < NUA ? hh * WIN + (x < R1 ? x : TJ + x) * LROW + HK + sp * SPAN + lane * VK : -1;
-    hfield[tt] = P.in[halo_input_of(HMASK, 0)];
-    static_for<NH>([&](auto hc) { constexpr int h = hc; if (hh == h) hfield[tt] = P.in[halo_input_of(HMASK, h)]; });
   });
   // halo cells beside my own rows: lanes [0,HK) the cells left of the window (its leftmost waves), lanes [HK,2HK) the
   // cells right of it (its rightmost waves); clamped per cell
   const bool kh_left = R2 > 0 && wk == 0 && lane < HK, kh_right = R2 > 0 && wk == WK - 1 && lane >= HK && lane < 2 * HK;
   const bool kh_any = kh_left || kh_right;
-  int32_t khc = kh_left ? kw0 - HK + lane : kw0 + TK + (lane - HK);
-  khc = khc < 0 ? 0 : (khc >= P.N2 ? P.N2 - 1 : khc);
-  const uint32_t kh_b = (uint32_t)khc * (uint32_t)sizeof(T);
+  const int32_t khc = kh_left ? kw0 - HK + lane : kw0 + TK + (lane - HK);
+  uint32_t kh_b[NV];
+  static_for<NV>([&](auto nc) { constexpr int n = nc; kh_b[n] = view_cell_bytes(P, n, khc); });
   const int32_t kh_dst = (R1 + wj * RJ) * LROW + (kh_left ? lane : HK + TK + (lane - HK));
 
   // ---- register state: per halo input the ring of own cells with the planes in flight; the halo pieces in flight ----
@@ -191,28 +193,24 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   T kh[NH][RJ];
   V pt[NIN][RJ];   // inputs read at the centre only: row r of the next plane is requested as soon as row r has been computed
 
-  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
-    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
-    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
-  };
   auto load_rows = [&](int32_t ip, auto slot_c) {
     constexpr int sl = decltype(slot_c)::value;
     static_for<NH>([&](auto hc) {
-      constexpr int h = hc;
-      const char* base = plane_base(P.in[halo_input_of(HMASK, h)], ip);
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[h][sl][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+      constexpr int h = hc, n = halo_input_of(HMASK, h);
+      const char* base = view_plane_base(P, n, ip);
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[h][sl][r] = *reinterpret_cast<const V*>(base + (rowb[vidx(n)][r] + lane_bv[vidx(n)])); });
     });
   };
   auto load_halos = [&](int32_t ip) {
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
-      if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(plane_base(hfield[tt], ip) + hsrc[tt]);
+      if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(view_plane_base(P, hin[tt], ip) + hsrc[tt]);
     });
     if constexpr (R2 > 0) {
       if (kh_any) static_for<NH>([&](auto hc) {
-        constexpr int h = hc;
-        const char* base = plane_base(P.in[halo_input_of(HMASK, h)], ip);
-        static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[h][r] = *reinterpret_cast<const T*>(base + (rowb[r] + kh_b)); });
+        constexpr int h = hc, n = halo_input_of(HMASK, h);
+        const char* base = view_plane_base(P, n, ip);
+        static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[h][r] = *reinterpret_cast<const T*>(base + (rowb[vidx(n)][r] + kh_b[vidx(n)])); });
       });
     }
   };
@@ -220,7 +218,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     constexpr int r = decltype(rc)::value;
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
-      if constexpr (!((HMASK >> n) & 1u)) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
+      if constexpr (!((HMASK >> n) & 1u)) pt[n][r] = *reinterpret_cast<const V*>(view_plane_base(P, n, ip) + (rowb[vidx(n)][r] + lane_bv[vidx(n)]));
     });
   };
 
@@ -316,7 +314,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
         res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
       if (row_ok[r] && lane_ok) {
-        V* dst = reinterpret_cast<V*>(obase + (rowb[r] + lane_b));
+        V* dst = reinterpret_cast<V*>(obase + (rowb[0][r] + lane_b));
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }
@@ -430,19 +428,19 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
   if (ib >= ie) return;
   const int64_t plane_b = (int64_t)P.N1 * P.N2 * (int64_t)sizeof(T);
 
-  auto row_bytes = [&](int32_t j) -> uint32_t {
-    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
-    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
-  };
-  auto cell_bytes = [&](int32_t k) -> uint32_t {
-    k = k < 0 ? 0 : (k >= P.N2 ? P.N2 - 1 : k);
-    return (uint32_t)k * (uint32_t)sizeof(T);
-  };
-  uint32_t rowb[RJ];
-  static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[r] = row_bytes(j0 + r); });
+  // own-row offsets: one set for the result and input 0, one per input when there are several (InView, apply_march.hpp)
+  constexpr int NV = NIN > 1 ? NIN : 1;
+  constexpr auto vidx = [](int n) constexpr { return NIN > 1 ? n : 0; };
+  auto row_bytes = [&](int32_t j) -> uint32_t { return view_row_bytes(P, HIN, j); };   // rows of the input read at offsets
+  uint32_t rowb[NV][RJ], lane_bv[NV];
+  static_for<NV>([&](auto nc) {
+    constexpr int n = nc;
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; rowb[n][r] = view_row_bytes(P, n, j0 + r); });
+    lane_bv[n] = view_lane_bytes(P, n, k0);
+  });
   // halo cells: lanes [0,HK) left of the window, lanes [HK,2HK) right of it (one cell each, clamped)
   const bool c_left = lane < HK, c_right = lane >= HK && lane < 2 * HK;
-  const uint32_t cell_b = cell_bytes(c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK));
+  const uint32_t cell_b = view_cell_bytes(P, HIN, c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK));
   const int32_t cell_col = c_left ? lane : HK + TK + (lane - HK);
   const bool kh_any = R2 > 0 && ((wk == 0 && c_left) || (wk == WK - 1 && c_right));
   const int32_t kh_dst = (R1 + wj * RJ) * LROW + cell_col;
@@ -457,7 +455,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
     const int32_t kc = kw0 + sp * SPAN + lane * VK;
     const uint32_t rb = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
     const int32_t lrow = (x < R1 ? x : TJ + x) * LROW;
-    hsrc[tt] = rb + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T);
+    hsrc[tt] = rb + view_lane_bytes(P, HIN, kc);
     hdst[tt] = u < NU ? lrow + HK + sp * SPAN + lane * VK : -1;
     hcsrc[tt] = rb + cell_b;
     hcdst[tt] = lrow + cell_col;
@@ -470,22 +468,18 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
   T kh[PF][RJ], hc[PF][NHWX];
   V pt[NIN][RJ];
 
-  auto plane_base = [&](const T* field, int32_t ip) -> const char* {
-    const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
-    return reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
-  };
   auto load_plane = [&](int32_t ip, auto dc) {
     constexpr int d = decltype(dc)::value;
-    const char* base = plane_base(P.in[HIN], ip);
+    const char* base = view_plane_base(P, HIN, ip);
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
       if (hdst[tt] >= 0) jh[d][tt] = *reinterpret_cast<const V*>(base + hsrc[tt]);
       if (hc_any[tt]) hc[d][tt] = *reinterpret_cast<const T*>(base + hcsrc[tt]);
     });
     if constexpr (R2 > 0) {
-      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[d][r] = *reinterpret_cast<const T*>(base + (rowb[r] + cell_b)); });
+      if (kh_any) static_for<RJ>([&](auto rc) { constexpr int r = rc; kh[d][r] = *reinterpret_cast<const T*>(base + (rowb[vidx(HIN)][r] + cell_b)); });
     }
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; nxt[d][r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b)); });
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; nxt[d][r] = *reinterpret_cast<const V*>(base + (rowb[vidx(HIN)][r] + lane_bv[vidx(HIN)])); });
   };
   const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;
   auto lay_out = [&](int b, auto dc) {
@@ -505,7 +499,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
     constexpr int r = decltype(rc)::value;
     static_for<NIN>([&](auto nc) {
       constexpr int n = nc;
-      if constexpr (n != HIN) pt[n][r] = *reinterpret_cast<const V*>(plane_base(P.in[n], ip) + (rowb[r] + lane_b));
+      if constexpr (n != HIN) pt[n][r] = *reinterpret_cast<const V*>(view_plane_base(P, n, ip) + (rowb[vidx(n)][r] + lane_bv[vidx(n)]));
     });
   };
 
@@ -560,7 +554,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
         res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
       });
       if (row_ok[r] && lane_ok) {
-        V* dst = reinterpret_cast<V*>(obase + (rowb[r] + lane_b));
+        V* dst = reinterpret_cast<V*>(obase + (rowb[0][r] + lane_b));
         if constexpr (NT) __builtin_nontemporal_store(res, dst);
         else *dst = res;
       }
@@ -662,16 +656,9 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
   const bool lane_ok = k0 < P.Ks;
   const uint32_t lane_b = (uint32_t)(k0 < P.Kl ? k0 : P.Kl) * (uint32_t)sizeof(T);
 
-  auto row_bytes = [&](int32_t j) -> uint32_t {
-    j = j < 0 ? 0 : (j >= P.N1 ? P.N1 - 1 : j);
-    return (uint32_t)j * (uint32_t)P.N2 * (uint32_t)sizeof(T);
-  };
-  auto cell_bytes = [&](int32_t k) -> uint32_t {
-    k = k < 0 ? 0 : (k >= P.N2 ? P.N2 - 1 : k);
-    return (uint32_t)k * (uint32_t)sizeof(T);
-  };
+  // rows / cells are addressed per input (InView, apply_march.hpp: inputs 1.. may live in boxes of their own)
   const bool c_left = lane < HK, c_right = lane >= HK && lane < 2 * HK;
-  const uint32_t cell_b = cell_bytes(c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK));
+  const int32_t cell_k = c_left ? kw0 - HK + lane : kw0 + TK + (lane - HK);
   const int32_t cell_col = c_left ? lane : HK + TK + (lane - HK);
   const bool kh_any = R2 > 0 && ((wk == 0 && c_left) || (wk == WK - 1 && c_right));
   const int32_t own_cell = (R1 + wj * RJ) * LROW + HK + wk * SPAN + lane * VK;
@@ -688,11 +675,13 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
   bool hc_any[NHWX];
   static_for<NH>([&](auto hcn) {
     constexpr int h = hcn;
-    const char* base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, h)]);
+    constexpr int n = halo_input_of(HMASK, h);
+    const char* base = reinterpret_cast<const char*>(P.in[n]);
+    const uint32_t cell_b = view_cell_bytes(P, n, cell_k);
     static_for<RJ>([&](auto rc) {
       constexpr int r = rc;
-      const uint32_t rb = row_bytes(j0 + r);
-      own[h][r] = *reinterpret_cast<const V*>(base + (rb + lane_b));
+      const uint32_t rb = view_row_bytes(P, n, j0 + r);
+      own[h][r] = *reinterpret_cast<const V*>(base + (rb + view_lane_bytes(P, n, k0)));
       if constexpr (R2 > 0) { if (kh_any) kh[h][r] = *reinterpret_cast<const T*>(base + (rb + cell_b)); }
     });
   });
@@ -702,22 +691,23 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
     const int hh = NU ? uu / NU : 0, u = NU ? uu % NU : 0;
     const int x = u / WK, sp = u % WK;
     const int32_t kc = kw0 + sp * SPAN + lane * VK;
-    const uint32_t rb = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
+    int n = halo_input_of(HMASK, 0);
+    static_for<NH>([&](auto hcn) { constexpr int h = hcn; if (hh == h) n = halo_input_of(HMASK, h); });
+    const uint32_t rb = view_row_bytes(P, n, x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
     const int32_t lrow = hh * WIN + (x < R1 ? x : TJ + x) * LROW;
     hdst[tt] = uu < NUA ? lrow + HK + sp * SPAN + lane * VK : -1;
     hcdst[tt] = lrow + cell_col;
     hc_any[tt] = FP::BOX && R2 > 0 && uu < NUA && ((sp == 0 && c_left) || (sp == WK - 1 && c_right));
-    const T* field = P.in[halo_input_of(HMASK, 0)];
-    static_for<NH>([&](auto hcn) { constexpr int h = hcn; if (hh == h) field = P.in[halo_input_of(HMASK, h)]; });
-    const char* base = reinterpret_cast<const char*>(field);
-    if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(base + (rb + (uint32_t)(kc < P.Kl ? kc : P.Kl) * (uint32_t)sizeof(T)));
-    if (hc_any[tt]) hc[tt] = *reinterpret_cast<const T*>(base + (rb + cell_b));
+    const char* base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, 0)]);
+    static_for<NH>([&](auto hcn) { constexpr int h = hcn; if (hh == h) base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, h)]); });
+    if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(base + (rb + view_lane_bytes(P, n, kc)));
+    if (hc_any[tt]) hc[tt] = *reinterpret_cast<const T*>(base + (rb + view_cell_bytes(P, n, cell_k)));
   });
   static_for<NIN>([&](auto nc) {
     constexpr int n = nc;
     if constexpr (!((HMASK >> n) & 1u)) {
       const char* base = reinterpret_cast<const char*>(P.in[n]);
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = *reinterpret_cast<const V*>(base + (row_bytes(j0 + r) + lane_b)); });
+      static_for<RJ>([&](auto rc) { constexpr int r = rc; pt[n][r] = *reinterpret_cast<const V*>(base + (view_row_bytes(P, n, j0 + r) + view_lane_bytes(P, n, k0))); });
     }
   });
 
@@ -757,7 +747,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
       res[e] = inside ? val : OutsideOf<Body, T>::apply(body, through);
     });
     if (j < P.rJ1 && lane_ok) {
-      V* dst = reinterpret_cast<V*>(obase + (row_bytes(j) + lane_b));
+      V* dst = reinterpret_cast<V*>(obase + (view_row_bytes(P, 0, j) + lane_b));
       if constexpr (NT) __builtin_nontemporal_store(res, dst);
       else *dst = res;
     }

@@ -84,6 +84,7 @@ struct Footprint {
   int nin = 0, rank = 0;
   int radius[4][3];      // all accesses
   int top_radius[4][3];  // unconditional accesses only; -1 = none
+  int top_lo[4][3], top_hi[4][3];  // ... as offsets: most negative / most positive; hi < lo = none
   bool box = false;
   int halo_input = -1;
   unsigned halo_mask = 0;
@@ -121,6 +122,11 @@ struct Emitter {
           if (a) ++nz;
           if (a > fp.radius[k][d]) fp.radius[k][d] = a;
           if (top && a > fp.top_radius[k][d]) fp.top_radius[k][d] = a;  // starts at -1: offset 0 counts
+          if (top) {
+            const int off = (int)op->offsets[fp.lead + d];
+            if (fp.top_hi[k][d] < fp.top_lo[k][d]) fp.top_lo[k][d] = fp.top_hi[k][d] = off;   // the first unconditional access
+            else { fp.top_lo[k][d] = std::min(fp.top_lo[k][d], off); fp.top_hi[k][d] = std::max(fp.top_hi[k][d], off); }
+          }
         }
         if (nz > 1) fp.box = true;
       }
@@ -272,7 +278,7 @@ struct Emitter {
     fp.lead = lead;
     fp.rank = rank - lead;
     for (int k = 0; k < 4; ++k)
-      for (int d = 0; d < 3; ++d) { fp.radius[k][d] = 0; fp.top_radius[k][d] = -1; }
+      for (int d = 0; d < 3; ++d) { fp.radius[k][d] = 0; fp.top_radius[k][d] = -1; fp.top_lo[k][d] = 1; fp.top_hi[k][d] = -1; }
     for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d < lead ? -(d + 1) : d - lead;
     for (int k = 0; k < nin; ++k) temp_index[blk.args[rank + k].name] = k;
     if (lead > 0) {
@@ -343,6 +349,30 @@ struct Emitter {
     return true;
   }
 
+  // reach of a fused explicit time step: the rhs body's unconditional accesses of the state, and the axpy's read of the centre
+  static std::string fused_reach(const Footprint& cfp, int rank) {
+    std::ostringstream o;
+    o << "{";
+    for (int side = 0; side < 2; ++side) {
+      o << (side ? ", {" : "{");
+      for (int k = 0; k < 4; ++k) {
+        o << (k ? ", {" : "{");
+        for (int d = 0; d < 3; ++d) {
+          int v = side ? -1 : 1;   // not accessed
+          if (k == 0 && d < rank) {
+            const bool any = cfp.top_hi[0][d] >= cfp.top_lo[0][d];
+            v = side ? std::max(any ? cfp.top_hi[0][d] : 0, 0) : std::min(any ? cfp.top_lo[0][d] : 0, 0);
+          }
+          o << (d ? ", " : "") << v;
+        }
+        o << "}";
+      }
+      o << "}";
+    }
+    o << "}";
+    return o.str();
+  }
+
   // reach of an apply along dim 0 (the slab axis), over all of its accesses
   static int halo0_of(const Footprint& fp) {
     int h = 0;
@@ -374,10 +404,16 @@ struct Emitter {
       << ((fp.box && fp.march_ok) ? "true" : "false") << ", " << (fp.march_ok ? "true" : "false");
     if (halo_inputs > 1 && fp.march_ok) o << ", 0x" << std::hex << halo_mask << std::dec << "u";
     o << ">;\n";
-    o << "static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
-    for (int k = 0; k < 4; ++k) {
-      o << (k ? ", {" : "{");
-      for (int d = 0; d < 3; ++d) o << (d ? ", " : "") << (k < nin && d < fp.rank ? fp.top_radius[k][d] : -1);
+    // what the unconditional accesses reach, per input and dimension: {most negative offsets}, {most positive} (hi < lo: none)
+    o << "static const neptune_hip::Reach kTopRadius_" << tag << " = {";
+    for (int side = 0; side < 2; ++side) {
+      o << (side ? ", {" : "{");
+      for (int k = 0; k < 4; ++k) {
+        o << (k ? ", {" : "{");
+        for (int d = 0; d < 3; ++d)
+          o << (d ? ", " : "") << (k < nin && d < fp.rank ? (side ? fp.top_hi[k][d] : fp.top_lo[k][d]) : (side ? -1 : 1));
+        o << "}";
+      }
       o << "}";
     }
     o << "};\n\n";
@@ -685,14 +721,7 @@ struct Emitter {
           const std::string ctag = op.callee + "_0";  // the tag emit_function gives the opdef's only apply
           o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee
             << "}: state + dt * rhs(state), rhs apply and axpy fused into one kernel\n";
-          o << "  static const int32_t kTopRadius_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
-          for (int k = 0; k < 4; ++k) {
-            o << (k ? ", {" : "{");
-            for (int d = 0; d < 3; ++d)
-              o << (d ? ", " : "") << (k == 0 && d < st.rank() ? std::max(cfp.top_radius[0][d], 0) : -1);  // the axpy reads the centre
-            o << "}";
-          }
-          o << "};\n";
+          o << "  static const neptune_hip::Reach kTopRadius_" << tag << " = " << fused_reach(cfp, st.rank()) << ";\n";
           o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << "};\n";
           const std::string body = "neptune_hip::ops::EulerFused<Body_" + ctag + ", " + T + ", " + std::to_string(st.rank()) + ">";
           o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<" << body << ", " << T << ", " << st.rank() << ", 1, FP_"
@@ -722,13 +751,7 @@ struct Emitter {
             if (lit_ok) {
               ai.geom_symbol = tag + "__geom";
               std::ostringstream& ge = geom_entries;
-              ge << "static const int32_t kTopRadiusG_" << tag << "[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {";
-              for (int k = 0; k < 4; ++k) {
-                ge << (k ? ", {" : "{");
-                for (int d = 0; d < 3; ++d) ge << (d ? ", " : "") << (k == 0 && d < st.rank() ? std::max(cfp.top_radius[0][d], 0) : -1);
-                ge << "}";
-              }
-              ge << "};\n";
+              ge << "static const neptune_hip::Reach kTopRadiusG_" << tag << " = " << fused_reach(cfp, st.rank()) << ";\n";
               const char* names[3] = {"", "2", "3"};
               const char* fns[3] = {"launch_apply", "launch_apply_twice", "launch_apply_thrice"};
               for (int v = 0; v < 3; ++v)

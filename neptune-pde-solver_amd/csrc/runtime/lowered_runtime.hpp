@@ -336,8 +336,7 @@ inline const neptune_hip_launch_cfg_t* launch_override() {
 // reaches into its inputs' ghost planes).
 template <class Body, class T, int RANK, int NIN, class FP>
 inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
-                     const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest,
-                     int halo0 = 0) {
+                     const neptune_hip::Reach& top_radius, const Val* dest, int halo0 = 0) {
   // slab mode: an apply that stays within its plane (halo0 == 0) and reads only values whose ghost
   // planes are good is computed on the ghost planes too, so a stencil apply may follow it without an
   // exchange; any other result has stale ghosts
@@ -409,7 +408,7 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const 
 // leading extent.  No slab mode (the slab axis would be a leading dimension).
 template <class Body, class T, int R, int NIN, class FP>
 inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
-                             const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], const Val* dest) {
+                             const neptune_hip::Reach& top_radius, const Val* dest) {
   static_assert(R > 3 && R <= kMaxBoxRank, "run_apply_batched: rank 4..6");
   constexpr int L = R - 3;
   if (sc.slab()) die(sc.name(), "neptune_ir.apply of rank > 3 is not lowered in slab mode");
@@ -609,7 +608,7 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
 template <class Body, class T, int RANK, int NIN, class FP>
 inline double run_apply_reduce_sum(Scope& sc, const Body& body, const Box& result_decl, const Box& bounds_decl,
                                    const Val* const* in,
-                                   const int32_t (&top_radius)[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK], int halo0,
+                                   const neptune_hip::Reach& top_radius, int halo0,
                                    const Box* reduce_decl) {
   sc.wait_pending();
   for (int k = 0; k < NIN; ++k)

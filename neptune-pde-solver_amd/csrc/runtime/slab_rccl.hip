@@ -218,6 +218,9 @@ neptune_hip_slab_plan_t* neptune_hip_slab_plan_create(neptune_hip_slab_comm_t* c
     // ahead of it, or the exchange runs AFTER the interior and the edge launches wait for it
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    // (NEPTUNE_HIP_COMM_PRIORITY=normal: the default priority, for A/B measurements)
+    const char* pe = getenv("NEPTUNE_HIP_COMM_PRIORITY");
+    if (pe && strcmp(pe, "normal") == 0) greatest = 0;
     if (hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
         hipEventCreateWithFlags(&p->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->halo_done, hipEventDisableTiming) != hipSuccess) {

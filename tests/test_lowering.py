@@ -99,7 +99,12 @@ def test_known_answer_module_lowers_with_scf_if_and_multiple_inputs():
     assert kinds["kat_resid"] == ("march", "star", 2) and kinds["kat_axpy"] == ("march", "pointwise", 2)
     assert "if (v_e) {" in src and "} else {" in src
     # accesses under scf.if are conditional: only the unconditional ones enter the plan-time bounds check
-    assert "kTopRadius_kat_resid_0[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {{-1, -1, -1}, {-1, -1, -1}" in src
+    # (reach = {most negative offsets}, {most positive}; hi < lo: the input is not accessed unconditionally)
+    assert "neptune_hip::Reach kTopRadius_kat_resid_0 = {{{1, 1, 1}, {1, 1, 1}, {1, 1, 1}, {1, 1, 1}}, {{-1, -1, -1}, {-1, -1, -1}" in src
+    # ... and an unconditional one-sided access keeps its sign: a face field read at [0] and [+1] reaches (0, +1)
+    import test_ownbox_gpu as ob
+    src2, _ = lowering.to_hip(ob.case_text("staggered_1d"))
+    assert "neptune_hip::Reach kTopRadius_resid_0 = {{{0, 1, 1}, {0, 1, 1}, {-2, 1, 1}, {1, 1, 1}}, {{0, -1, -1}, {1, -1, -1}, {2, -1, -1}, {-1, -1, -1}}}" in src2
     assert "a.template idx<0>()" in src
 
 
@@ -266,7 +271,7 @@ def test_explicit_time_advance_lowers_and_implicit_stays_on_the_host():
     # the rhs opdef is one apply of the state: rhs and axpy run as ONE kernel over the state
     assert "lap__impl(sc, v_u0" not in src
     assert "nl::run_apply<neptune_hip::ops::EulerFused<Body_lap_0, double, 2>, double, 2, 1, FP_lap_0>" in src
-    assert "kTopRadius_step_ta0[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {{1, 1, -1}" in src
+    assert "neptune_hip::Reach kTopRadius_step_ta0 = {{{-1, -1, 1}, {1, 1, 1}" in src and "}}, {{1, 1, -1}, {-1, -1, -1}" in src
     assert [a["inputs"] for a in report["applies"] if a["function"] == "step"] == [1]
     # a rhs opdef made of two applies is not fusable: call @rhs, then the axpy apply
     src2, rep2s = lowering.to_hip((helpers.REPO / "tests/mlir_tests/time_stepping/explicit-twostage-3d.mlir").read_text())
