@@ -458,38 +458,52 @@ def main():
                 ok = ranks_agree(exchange_is_correct(torch_p2p, "torch.distributed point-to-point exchange"))
             verdicts[name] = {"ok": ok}
             if ok:
-                dog.stage(f"timing a few steps on the '{name}' transport", args.startup_timeout)
-                op = make_op(comm=comm)
-                try:
-                    verdicts[name]["ms_per_step"] = time_steps(op, 10, 3)
-                    if comm is not None:
-                        comm.status()
-                    comms[name], ops[name] = comm, op
-                except Exception as e:                  # noqa: BLE001
-                    print(f"[bench] rank {rank}: {name} steps: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
-                    verdicts[name] = {"ok": False, "error": "steps failed"}
-                    ok = False
-                if not ranks_agree(ok):
-                    verdicts[name]["ok"] = False
-                    comms.pop(name, None)
-                    ops.pop(name, None)
+                # ... with the communication stream at the greatest and at the default priority: on one GPU (loop-back) RCCL's
+                # copy kernels at the greatest priority slow the interior down more than they gain; between devices the
+                # exchange is bound by the link and should start first.  Measured, not guessed.
+                for prio in ("high", "normal"):
+                    key = f"{name}/{prio}"
+                    dog.stage(f"timing a few steps on the '{key}' transport", args.startup_timeout)
+                    os.environ["NEPTUNE_HIP_COMM_PRIORITY"] = prio       # read when the plan / stream is created: the first step
+                    op = make_op(comm=comm)
+                    good = True
+                    try:
+                        verdicts[key] = {"ok": True, "ms_per_step": time_steps(op, 10, 3)}
+                        if comm is not None:
+                            comm.status()
+                    except Exception as e:                  # noqa: BLE001
+                        print(f"[bench] rank {rank}: {key} steps: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                        good = False
+                    if ranks_agree(good):
+                        comms[key], ops[key] = comm, op
+                    else:
+                        verdicts[key] = {"ok": False, "error": "steps failed"}
+                        del op
+                if not any(k.startswith(name + "/") for k in ops) and comm is not None:
+                    torch.cuda.synchronize()
+                    comm.close()
             elif comm is not None:
                 comm.close()
             dog.done()
-        usable = [n for n in wanted if n in ops]
+        os.environ.pop("NEPTUNE_HIP_COMM_PRIORITY", None)
+        usable = [k for k in ops]
         if usable:
-            chosen = min(usable, key=lambda n: verdicts[n]["ms_per_step"])
+            chosen = min(usable, key=lambda k: verdicts[k]["ms_per_step"])
             if world > 1:    # every rank holds the same max-over-ranks times, but agree explicitly
-                pick = torch.tensor([wanted.index(chosen)], dtype=torch.int32, device=coll_dev)
+                pick = torch.tensor([usable.index(chosen)], dtype=torch.int32, device=coll_dev)
                 dist.broadcast(pick, 0)
-                chosen = wanted[int(pick.item())]
-            transport = DESCR[chosen]
-            for n in usable:
-                if n != chosen:
-                    ops.pop(n)
-                    torch.cuda.synchronize()
-                    if comms.get(n) is not None:
-                        comms.pop(n).close()
+                chosen = usable[int(pick.item())]
+            transport = DESCR[chosen.split("/")[0]] + f"; communication stream priority: {chosen.split('/')[1]}"
+            keep = comms[chosen]
+            for k in usable:
+                if k != chosen:
+                    ops.pop(k)
+            torch.cuda.synchronize()
+            import gc
+            gc.collect()
+            for c in {id(c): c for k, c in comms.items() if c is not None and c is not keep}.values():
+                c.close()
+            comms = {chosen: keep}
         elif args.rehearse_on_one_gpu and args.halo_transport == "torch":
             transport = "gloo-host-staged (rehearsal)"
         elif not args.allow_host_staging:

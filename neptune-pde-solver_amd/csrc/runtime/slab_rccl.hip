@@ -213,14 +213,19 @@ neptune_hip_slab_plan_t* neptune_hip_slab_plan_create(neptune_hip_slab_comm_t* c
     if (r_hi > 0 && radius > 0) p->edges[p->n_edges++] = region(ihi, hi);
   }
   if (r_lo > 0 || r_hi > 0) {
-    // greatest priority: the exchange and the interior launch become runnable at the same instant (both wait for the
-    // previous step), and the interior grid fills every CU -- the RCCL kernels / handshake waves must be dispatched
-    // ahead of it, or the exchange runs AFTER the interior and the edge launches wait for it
+    // Priority of the communication stream.  The exchange and the interior launch become runnable at the same instant
+    // (both wait for the previous step) and the interior grid fills every CU, so the exchange's kernels must not be
+    // dispatched BEHIND it, or the exchange runs after the interior and the edge launches wait for it.  Peer transport:
+    // greatest priority -- its two handshake waves cost nothing and the copies run on the SDMA engines.  RCCL: default
+    // priority -- its copy kernels at the greatest priority took the interior's CUs on one GPU (loop-back, 1024^3 slab
+    // of 8: step 0.56 ms against 0.39 ms; both ran beside the interior, profiles/r03_multigpu.txt); between devices the
+    // exchange is bound by the link and may want the head start: NEPTUNE_HIP_COMM_PRIORITY=high|normal overrides, and
+    // bench.py times both.
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
-    // (NEPTUNE_HIP_COMM_PRIORITY=normal: the default priority, for A/B measurements)
     const char* pe = getenv("NEPTUNE_HIP_COMM_PRIORITY");
-    if (pe && strcmp(pe, "normal") == 0) greatest = 0;
+    const bool high = pe && *pe ? strcmp(pe, "normal") != 0 : (comm && comm->transport == NEPTUNE_HIP_TRANSPORT_PEER);
+    if (!high) greatest = 0;
     if (hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
         hipEventCreateWithFlags(&p->ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&p->halo_done, hipEventDisableTiming) != hipSuccess) {

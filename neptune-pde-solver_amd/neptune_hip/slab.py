@@ -265,7 +265,11 @@ class ShardedApply:
         self.overlap = overlap
         self.interior, self.edges = slab.regions()
         self.compute = torch.cuda.current_stream()
-        self.comm = torch.cuda.Stream(priority=-1)   # dispatched ahead of the CU-filling interior launch
+        # the stream of the torch.distributed route (RCCL): default priority unless NEPTUNE_HIP_COMM_PRIORITY=high -- the C
+        # plan's rule for the RCCL transport (csrc/runtime/slab_rccl.hip: copy kernels at the greatest priority take the
+        # interior's CUs on one GPU; between devices the head start may pay: bench.py measures both)
+        import os
+        self.comm = torch.cuda.Stream(priority=-1 if os.environ.get("NEPTUNE_HIP_COMM_PRIORITY") == "high" else 0)
         self.ready = torch.cuda.Event()
         self.halo_done = torch.cuda.Event()
         self._cache = {}
@@ -432,7 +436,8 @@ class ShardedModule:
         if staged or not self.overlap or not all(t.is_cuda for t in tensors):
             return False
         if self._comm_stream is None:
-            self._comm_stream = torch.cuda.Stream(priority=-1)
+            import os
+            self._comm_stream = torch.cuda.Stream(priority=-1 if os.environ.get("NEPTUNE_HIP_COMM_PRIORITY") == "high" else 0)
             self._ready, self._halo_done = lib.neptune_hip_event_create(), lib.neptune_hip_event_create()
             self._ready0 = lib.neptune_hip_event_create()
         cur = int(torch.cuda.current_stream().cuda_stream)
