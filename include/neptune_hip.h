@@ -257,10 +257,12 @@ int neptune_hip_step_loop(neptune_hip_apply_fn fn, int body, const neptune_hip_a
 
 /* Several steps per pass over HBM.  neptune_hip_apply_chain_builtin computes out = A(A(in)) (applies = 2) or A(A(A(in)))
  * (applies = 3) for built-in body A in ONE launch -- the intermediate fields exist in registers only; the same operations on
- * the same operands as separate launches, hence the same bits.  Scope: single-input radius-1 stars of rank 3 (the 7-point
- * family) and of rank 2 (the 5-point family: neptune_apply_march2_rank2), the fused explicit Euler step of such an operator
- * included, when the geometry qualifies (all boxes equal, rows a whole number of 64-byte granules, launch region restricted
- * along dim 0 only); otherwise NEPTUNE_HIP_EUNSUPPORTED and nothing is launched.  neptune_hip_apply2_builtin is the
+ * the same operands as separate launches, hence the same bits.  Scope: rank 3: star footprints of input 0 up to radius 2
+ * per axis (the 7-point family: two or three applies per pass; 13-point 4th-order operators: two), the fused explicit
+ * Euler step of such an operator included, and -- for lowered applies -- further inputs read at the centre only
+ * (coefficient fields: in[1..], the same field at every stage); rank 2: the single-input 5-point family
+ * (neptune_apply_march2_rank2); when the geometry qualifies (all boxes equal, rows a whole number of 64-byte granules,
+ * launch region restricted along dim 0 only); otherwise NEPTUNE_HIP_EUNSUPPORTED and nothing is launched.  neptune_hip_apply2_builtin is the
  * applies = 2 form.  Lowered applies export the same as <function>_<k>__geom2 / __geom3.
  * neptune_hip_step_loop uses them for the built-in bodies ON ITS OWN for fields of NEPTUNE_HIP_CHAIN_MIN_CELLS cells
  * (default 4e6) and more; neptune_hip_step_loop_chain is the same loop with a lowered apply's pair / triple entries `fn2`,

@@ -9,9 +9,10 @@
 // are exactly those of two separate launches (the body functor is evaluated once per cell and stage, strict IEEE,
 // no contraction), hence the same bits.
 //
-// Scope: rank 3, one input, star footprint of radius 1 (the 7-point family, the fused explicit Euler step of such an
-// operator included), all boxes equal, rows a whole number of 64-byte store granules.  Everything else keeps using
-// two launches (neptune_hip_step_loop decides).
+// Scope: rank 3: star footprints of input 0 up to radius 2 per axis (the 7-point family, the fused explicit Euler step of
+// such an operator included; 13-point 4th-order operators: two applies per pass), further inputs read at the centre only
+// (coefficient fields: the same field at every stage); rank 2: the 5-point family.  All boxes equal, rows a whole number of
+// 64-byte store granules.  Everything else keeps using one launch per apply (neptune_hip_step_loop decides).
 //
 // Shape of the march (one workgroup = WJ waves stacked along J, one wave span wide):
 //   * a wave owns RJ rows x 64 lane vectors; the workgroup's window is TJ = WJ*RJ rows x 64*VK cells.
@@ -31,9 +32,9 @@
 
 namespace neptune_hip {
 
-template <class T>
+template <class T, int NIN>
 struct March2Params {
-  const T* in;
+  const T* in[NIN];        // in[0]: the field the applies chain on; in[1..]: inputs read at the centre only, the same at every stage
   T* out;
   int32_t N0, N1, N2;
   int32_t plb[3], pub[3];  // apply.bounds, result-physical
@@ -43,23 +44,40 @@ struct March2Params {
   uint32_t nJ, nK;
 };
 
+// window constants of a footprint: each stage loses R1 rows / R2 columns / R0 planes of validity per side
+template <class T, class FP, int NS>
+struct March2Geom {
+  static constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T);   // cells per lane vector / per 64-byte store granule
+  static constexpr int R0 = FP::R0, R1 = FP::R1, R2 = FP::R2;
+  // kept columns start MK cells inside the window: a whole number of half granules (so that both ends of the kept span are
+  // granule boundaries: SPAN - 2 MK is a multiple of G) and of lane vectors, at least NS * R2
+  static constexpr int HG = G / 2 > VK ? G / 2 : VK;
+  static constexpr int MK = (NS * R2 + HG - 1) / HG * HG;
+  static constexpr int SPAN = kWave * VK, KEEPK = SPAN - 2 * MK;
+  static constexpr int MJ = NS * R1;                                        // rows lost per side
+  static constexpr int WARM = 2 * R0 * (NS - 1);                            // planes a chunk starts early
+};
+
 // NS chained applies per pass (2 or 3); RJ rows per lane, WJ waves per workgroup, MINW = waves per SIMD the register
 // allocation must leave room for.  Stage k = 1..NS computes v_k = A(v_{k-1}) (v_0 = the input u, v_NS = the result w);
-// at step i stage k produces plane i + NS - k, so each stage's newest plane is the next stage's upper neighbour plane
-// within the same step.  v_k is valid k cells / rows inside the window.
-template <class Body, class T, class FP, int NS, int RJ, int WJ, int MINW>
-__global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Params<T> P, Body body) {
+// at step i stage k produces plane i + (NS - k) R0, so each stage's newest plane is the next stage's farthest upper
+// neighbour plane within the same step.  v_k is valid k R cells / rows inside the window.
+// Star footprints of input 0 up to radius 2 per axis (7-point family, 13-point 4th-order operators); inputs 1.. are read at
+// the centre only and are the same field at every stage (coefficient fields): each keeps a queue of the (NS-1) R0 + 1 planes
+// between the first stage's plane and the last one's.
+template <class Body, class T, int NIN, class FP, int NS, int RJ, int WJ, int MINW>
+__global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Params<T, NIN> P, Body body) {
   using V = typename Vec16<T>::type;
-  constexpr int VK = 16 / sizeof(T);
+  using GM = March2Geom<T, FP, NS>;
+  constexpr int VK = GM::VK, R0 = GM::R0, R1 = GM::R1, R2 = GM::R2, NP = 2 * R0 + 1;
   static_assert(NS >= 2 && NS <= 3, "two or three applies per pass");
   constexpr int TJ = RJ * WJ;                 // window rows
-  constexpr int KEEPJ = TJ - 2 * NS;          // rows of w this workgroup stores: [Jb + NS, Jb + TJ - NS)
-  constexpr int G = 64 / (int)sizeof(T);      // cells per 64-byte store granule
-  constexpr int SPAN = kWave * VK;            // window columns
-  constexpr int KEEPK = SPAN - G;             // columns of w this wave stores: [kw + G/2, kw + SPAN - G/2)
-  static_assert((G / 2) % VK == 0 && G / 2 >= NS, "the kept columns must start at a whole lane, NS cells inside");
-  static_assert(FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u, "radius-1 star of input 0");
-  __shared__ V lds[2][WJ][2 * NS][kWave];     // [parity][wave][stage input k: first own row, last own row][lane]
+  constexpr int MK = GM::MK, SPAN = GM::SPAN;
+  static_assert(R0 >= 1 && R0 <= 2 && R1 >= 1 && R1 <= 2 && R2 >= 1 && R2 <= 2 && !FP::BOX && FP::HALO_MASK == 1u, "star of input 0, radius 1..2");
+  static_assert(RJ >= R1 && R2 <= VK && TJ > 2 * GM::MJ, "window too small for the footprint");
+  constexpr int NQ = (NS - 1) * R0 + 1;       // planes of a centre-only input between the first stage's plane and the last one's
+  constexpr int NF = NIN > 1 ? NIN - 1 : 1;
+  __shared__ V lds[2][WJ][NS][2 * R1][kWave];  // [parity][wave][stage input k][first R1 own rows | last R1 own rows][lane]
 
   const int lane = threadIdx.x & (kWave - 1);
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -69,9 +87,9 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   const uint32_t jt = t % P.nJ;
   const uint32_t ct = t / P.nJ;
 
-  const int32_t Jb = (int32_t)(jt * KEEPJ) - NS;         // first row of the window
-  const int32_t j0 = Jb + w * RJ;                        // first own row
-  const int32_t kw = (int32_t)(kt * KEEPK) - G / 2;      // first column of the window
+  const int32_t Jb = (int32_t)(jt * (TJ - 2 * GM::MJ)) - GM::MJ;   // first row of the window
+  const int32_t j0 = Jb + w * RJ;                                    // first own row
+  const int32_t kw = (int32_t)(kt * GM::KEEPK) - MK;                 // first column of the window
   const int32_t k0 = kw + lane * VK;
   // loads: clamped into the field (a clamped cell only ever feeds values that are discarded)
   const int32_t kc = k0 < 0 ? 0 : (k0 > P.N2 - VK ? P.N2 - VK : k0);
@@ -89,9 +107,9 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
   if (ib >= ie) return;
 
-  auto load_plane = [&](int32_t ip, V(&rows)[RJ]) {
+  auto load_plane = [&](const T* field, int32_t ip, V(&rows)[RJ]) {
     const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
-    const char* base = reinterpret_cast<const char*>(P.in) + (int64_t)ic * plane_b;
+    const char* base = reinterpret_cast<const char*>(field) + (int64_t)ic * plane_b;
     static_for<RJ>([&](auto rc) {
       constexpr int r = rc;
       rows[r] = *reinterpret_cast<const V*>(base + (rowb[r] + lane_b));
@@ -103,33 +121,41 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
   static_for<RJ>([&](auto rc) {
     constexpr int r = rc;
     const int32_t j = j0 + r;
-    row_keep[r] = j >= Jb + NS && j < Jb + TJ - NS && j >= 0 && j < P.N1;
+    row_keep[r] = j >= Jb + GM::MJ && j < Jb + TJ - GM::MJ && j >= 0 && j < P.N1;
     in_j[r] = j >= P.plb[1] && j < P.pub[1];
   });
   static_for<VK>([&](auto ec) {
     constexpr int e = ec;
     in_k[e] = (k0 + e) >= P.plb[2] && (k0 + e) < P.pub[2];
   });
-  const bool lane_keep = k0 >= kw + G / 2 && k0 < kw + SPAN - G / 2 && k0 >= 0 && k0 < P.N2;
+  const bool lane_keep = k0 >= kw + MK && k0 < kw + SPAN - MK && k0 >= 0 && k0 < P.N2;
 
-  // one stage: `ctr` = the centre plane's own rows, `above` / `below` its J-halo rows, lo / hi the planes before / after
-  auto stage = [&](const V(&lo)[RJ], const V(&ctr)[RJ], const V(&hi)[RJ], const V& above, const V& below, int32_t ip,
+  // one stage: `pl` = the 2 R0 + 1 planes of the stage's input (own rows), centre at pl[R0]; `above` / `below` the R1 rows
+  // outside the wave's own rows on the centre plane; `fx` the centre-only inputs' rows on the stage's plane
+  auto stage = [&](const V(&pl)[NP][RJ], const V(&above)[R1], const V(&below)[R1], const V(&fx)[NF][NQ][RJ], auto qc, int32_t ip,
                    V(&res)[RJ]) {
-    V ring[1][3][RJ + 2];
-    T lft[1][1][RJ + 2][1], rgt[1][1][RJ + 2][1];
-    V pt[1][RJ];
+    constexpr int q = decltype(qc)::value;
+    V ring[1][NP][RJ + 2 * R1];
+    T lft[1][1][RJ + 2 * R1][R2], rgt[1][1][RJ + 2 * R1][R2];
+    V pt[NIN][RJ];
     static_for<RJ>([&](auto rc) {
       constexpr int r = rc;
-      ring[0][0][r + 1] = lo[r];
-      ring[0][1][r + 1] = ctr[r];
-      ring[0][2][r + 1] = hi[r];
+      static_for<NP>([&](auto pc) { constexpr int pp = pc; ring[0][pp][r + R1] = pl[pp][r]; });
       // K neighbours from the adjacent lanes; the wave's outermost cells get an arbitrary edge value: their results
-      // are two cells outside the kept columns
-      lft[0][0][r + 1][0] = from_prev<true>(ctr[r][VK - 1], ctr[r][0], lane);
-      rgt[0][0][r + 1][0] = from_next<true>(ctr[r][0], ctr[r][VK - 1], lane);
+      // lie outside the kept columns
+      static_for<R2>([&](auto xc) {
+        constexpr int x = xc;
+        constexpr int dl = R2 - x, dr = x + 1;
+        lft[0][0][r + R1][x] = from_prev<true>(pl[R0][r][VK - dl], pl[R0][r][0], lane);
+        rgt[0][0][r + R1][x] = from_next<true>(pl[R0][r][dr - 1], pl[R0][r][VK - 1], lane);
+      });
+      static_for<NIN>([&](auto nc) { constexpr int n = nc; if constexpr (n > 0) pt[n][r] = fx[n - 1][q][r]; });
     });
-    ring[0][1][0] = above;
-    ring[0][1][RJ + 1] = below;
+    static_for<R1>([&](auto xc) {
+      constexpr int x = xc;
+      ring[0][R0][x] = above[x];
+      ring[0][R0][RJ + R1 + x] = below[x];
+    });
     const bool in_i = ip >= P.plb[0] && ip < P.pub[0];
     const int64_t li = (int64_t)ip + P.olb[0];
     static_for<RJ>([&](auto rc) {
@@ -138,52 +164,72 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
       static_for<VK>([&](auto ec) {
         constexpr int e = ec;
         const int64_t lk = (int64_t)(k0 + e) + P.olb[2];
-        MarchAcc<T, 3, 1, FP, RJ, r, e, false> acc{ring, lft, rgt, pt, li, lj, lk};
+        MarchAcc<T, 3, NIN, FP, RJ, r, e, false> acc{ring, lft, rgt, pt, li, lj, lk};
         const T val = body(acc);
-        const T through = ctr[r][e];
+        const T through = pl[R0][r][e];
         res[r][e] = (in_i && in_j[r] && in_k[e]) ? val : OutsideOf<Body, T>::apply(body, through);
       });
     });
   };
 
-  // ---- register state.  ring[k] holds the three newest planes of v_k that stage k+1 reads: at step i these are planes
-  // i+NS-k-2, i+NS-k-1 (the centre of stage k+1), i+NS-k; ring[k][2] is written by stage k in the same step (k = 0: by
-  // the load issued one step earlier).
-  V ring[NS][3][RJ];
-  V un[RJ];                                // u(i + NS + 1) in flight
+  // ---- register state.  ring[k] holds the 2 R0 + 1 newest planes of v_k that stage k+1 reads: at step i planes
+  // i + (NS-k) R0 - 2 R0 .. i + (NS-k) R0, the centre of stage k+1 in the middle; ring[k][2 R0] is written by stage k in the
+  // same step (k = 0: by the load issued one step earlier).  fx[n][q]: plane i + q R0 ... of centre-only input n+1: slot q is
+  // the plane of the stage that works q R0 planes ahead of the last one.
+  V ring[NS][NP][RJ];
+  V un[RJ];                                // u(i + NS R0 + 1) in flight
+  V fx[NF][NQ][RJ], fn[NF][RJ];            // centre-only inputs: queue and the plane in flight
   V wres[RJ];
-  const int32_t i0 = ib - 2 * (NS - 1);    // warm-up steps fill the rings of the intermediate fields (their w is discarded)
-  load_plane(i0 + NS - 2, ring[0][0]);
-  load_plane(i0 + NS - 1, ring[0][1]);
-  load_plane(i0 + NS, un);
+  const int32_t i0 = ib - GM::WARM;        // warm-up steps fill the rings of the intermediate fields (their w is discarded)
+  static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; load_plane(P.in[0], i0 + NS * R0 - 2 * R0 + pp, ring[0][pp]); });
+  load_plane(P.in[0], i0 + NS * R0, un);
+  if constexpr (NIN > 1) {
+    static_for<NIN - 1>([&](auto nc) {
+      constexpr int n = nc;
+      static_for<NQ - 1>([&](auto qc) { constexpr int q = qc; load_plane(P.in[n + 1], i0 + q, fx[n][q]); });
+      load_plane(P.in[n + 1], i0 + NQ - 1, fn[n]);
+    });
+  }
   static_for<NS - 1>([&](auto kc) {        // defined, never part of a kept result
     constexpr int k = kc + 1;
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][0][r] = ring[0][0][r]; ring[k][1][r] = ring[0][0][r]; });
+    static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][pp][r] = ring[0][0][r]; }); });
   });
 
   for (int32_t i = i0; i < ie; ++i) {
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[0][2][r] = un[r]; });
-    // J-halo rows of every stage's centre plane: publish my first / last own rows, take the neighbouring waves'
+    static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[0][NP - 1][r] = un[r]; });
+    if constexpr (NIN > 1)
+      static_for<NIN - 1>([&](auto nc) { constexpr int n = nc; static_for<RJ>([&](auto rc) { constexpr int r = rc; fx[n][NQ - 1][r] = fn[n][r]; }); });
+    // J-halo rows of every stage's centre plane: publish my first / last R1 own rows, take the neighbouring waves'
     const int buf = (i - i0) & 1;
     static_for<NS>([&](auto kc) {
       constexpr int k = kc;
-      lds[buf][w][2 * k][lane] = ring[k][1][0];
-      lds[buf][w][2 * k + 1][lane] = ring[k][1][RJ - 1];
+      static_for<R1>([&](auto xc) {
+        constexpr int x = xc;
+        lds[buf][w][k][x][lane] = ring[k][R0][x];
+        lds[buf][w][k][R1 + x][lane] = ring[k][R0][RJ - R1 + x];
+      });
     });
     __syncthreads();
-    V above[NS], below[NS];
+    V above[NS][R1], below[NS][R1];
     static_for<NS>([&](auto kc) {
       constexpr int k = kc;
-      above[k] = ring[k][1][0];            // window-edge waves: any value (those rows are not kept)
-      below[k] = ring[k][1][RJ - 1];
-      if (w > 0) above[k] = lds[buf][w - 1][2 * k + 1][lane];
-      if (w < WJ - 1) below[k] = lds[buf][w + 1][2 * k][lane];
+      static_for<R1>([&](auto xc) {
+        constexpr int x = xc;
+        above[k][x] = ring[k][R0][0];        // window-edge waves: any value (those rows are not kept)
+        below[k][x] = ring[k][R0][RJ - 1];
+        if (w > 0) above[k][x] = lds[buf][w - 1][k][R1 + x][lane];      // row j0 - R1 + x = the wave above's last R1 rows
+        if (w < WJ - 1) below[k][x] = lds[buf][w + 1][k][x][lane];      // row j0 + RJ + x = the wave below's first R1 rows
+      });
     });
-    if (i + NS + 1 <= ie + NS - 1) load_plane(i + NS + 1, un);   // u(ie - 1 + NS) is the last plane a kept result depends on
+    if (i + NS * R0 + 1 <= ie - 1 + NS * R0) {   // u(ie - 1 + NS R0) is the last plane a kept result depends on
+      load_plane(P.in[0], i + NS * R0 + 1, un);
+      if constexpr (NIN > 1) static_for<NIN - 1>([&](auto nc) { constexpr int n = nc; load_plane(P.in[n + 1], i + NQ, fn[n]); });
+    }
     static_for<NS>([&](auto kc) {
-      constexpr int k = kc;                // stage k + 1: v_{k+1}(i + NS - k - 1) from ring[k]
-      if constexpr (k + 1 < NS) stage(ring[k][0], ring[k][1], ring[k][2], above[k], below[k], i + NS - k - 1, ring[k + 1][2]);
-      else stage(ring[k][0], ring[k][1], ring[k][2], above[k], below[k], i, wres);
+      constexpr int k = kc;                // stage k + 1: v_{k+1}(i + (NS - k - 1) R0) from ring[k]
+      constexpr int q = (NS - k - 1) * R0;
+      if constexpr (k + 1 < NS) stage(ring[k], above[k], below[k], fx, std::integral_constant<int, q>{}, i + q, ring[k + 1][NP - 1]);
+      else stage(ring[k], above[k], below[k], fx, std::integral_constant<int, 0>{}, i, wres);
     });
     if (i >= ib && lane_keep) {
       char* obase = reinterpret_cast<char*>(P.out) + (int64_t)i * plane_b;
@@ -194,8 +240,13 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
     }
     static_for<NS>([&](auto kc) {
       constexpr int k = kc;
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][0][r] = ring[k][1][r]; ring[k][1][r] = ring[k][2][r]; });
+      static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; static_for<RJ>([&](auto rc) { constexpr int r = rc; ring[k][pp][r] = ring[k][pp + 1][r]; }); });
     });
+    if constexpr (NIN > 1)
+      static_for<NIN - 1>([&](auto nc) {
+        constexpr int n = nc;
+        static_for<NQ - 1>([&](auto qc) { constexpr int q = qc; static_for<RJ>([&](auto rc) { constexpr int r = rc; fx[n][q][r] = fx[n][q + 1][r]; }); });
+      });
   }
 }
 
@@ -339,35 +390,43 @@ inline int launch_march2_rank2(const Body& body, const neptune_hip_apply_geom_t*
   return NEPTUNE_HIP_OK;
 }
 
-// host side: can this geometry take the two-steps kernel, and launch it
-template <class T, class FP>
-inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* in, const void* out) {
+// host side: can this geometry take the chain kernel, and launch it
+template <class FP>
+constexpr bool march2_footprint() {
+  return FP::MARCH_OK && !FP::BOX && FP::HALO_MASK == 1u && FP::R0 >= 1 && FP::R0 <= 2 && FP::R1 >= 1 && FP::R1 <= 2 && FP::R2 >= 1 && FP::R2 <= 2;
+}
+template <class T, int NIN, class FP>
+inline bool march2_eligible(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out) {
   constexpr int G = 64 / (int)sizeof(T);
-  if (!g || g->rank != 3 || g->num_inputs != 1) return false;
-  if (!(FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u)) return false;
+  if (!g || g->rank != 3 || g->num_inputs != NIN) return false;
+  if (!march2_footprint<FP>()) return false;
   int64_t n[3];
   for (int d = 0; d < 3; ++d) {
     n[d] = g->out_ub[d] - g->out_lb[d];
-    if (g->in_lb[0][d] != g->out_lb[d] || g->in_ub[0][d] != g->out_ub[d]) return false;
+    for (int k = 0; k < NIN; ++k)
+      if (g->in_lb[k][d] != g->out_lb[d] || g->in_ub[k][d] != g->out_ub[d]) return false;
     if (d > 0 && (g->region_lb[d] != 0 || g->region_ub[d] != n[d])) return false;
   }
   if (n[2] % G != 0 || n[2] < 2 * G || n[1] < 8 || n[0] < 1) return false;   // rows = whole 64-byte granules
   if (n[1] * n[2] * (int64_t)sizeof(T) >= 0x7fffffffLL) return false;         // 32-bit in-plane offsets
-  if ((uintptr_t)in % 64 != 0 || (uintptr_t)out % 64 != 0) return false;
+  if ((uintptr_t)out % 64 != 0) return false;
+  for (int k = 0; k < NIN; ++k)
+    if (!in[k] || (uintptr_t)in[k] % 64 != 0) return false;
   // the second apply re-reads what the first one copied through: only sound when every access of an in-bounds cell
   // stays inside the box (the same rule every plan obeys)
+  const int r[3] = {FP::R0, FP::R1, FP::R2};
   for (int d = 0; d < 3; ++d)
-    if (g->lb[d] < g->ub[d] && (g->lb[d] - 1 < g->out_lb[d] || g->ub[d] + 1 > g->out_ub[d])) return false;
+    if (g->lb[d] < g->ub[d] && (g->lb[d] - r[d] < g->out_lb[d] || g->ub[d] + r[d] > g->out_ub[d])) return false;
   return true;
 }
 
-template <class Body, class T, class FP, int NS, int RJ, int WJ, int MINW>
-inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+template <class Body, class T, int NIN, class FP, int NS, int RJ, int WJ, int MINW>
+inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out, hipStream_t stream,
                                int chunk_req) {
-  constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T);
-  constexpr int KEEPJ = RJ * WJ - 2 * NS, KEEPK = kWave * VK - G;
-  March2Params<T> P{};
-  P.in = static_cast<const T*>(in);
+  using GM = March2Geom<T, FP, NS>;
+  constexpr int KEEPJ = RJ * WJ - 2 * GM::MJ, KEEPK = GM::KEEPK;
+  March2Params<T, NIN> P{};
+  for (int k = 0; k < NIN; ++k) P.in[k] = static_cast<const T*>(in[k]);
   P.out = static_cast<T*>(out);
   P.N0 = (int32_t)(g->out_ub[0] - g->out_lb[0]);
   P.N1 = (int32_t)(g->out_ub[1] - g->out_lb[1]);
@@ -390,42 +449,57 @@ inline int launch_march2_shape(const Body& body, const neptune_hip_apply_geom_t*
   P.chunk = (int32_t)chunk;
   const int64_t blocks = (int64_t)P.nJ * P.nK * ((planes + chunk - 1) / chunk);
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
-  hipLaunchKernelGGL((neptune_apply_march2<Body, T, FP, NS, RJ, WJ, MINW>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P,
+  hipLaunchKernelGGL((neptune_apply_march2<Body, T, NIN, FP, NS, RJ, WJ, MINW>), dim3((uint32_t)blocks), dim3(kWave * WJ), 0, stream, P,
                      body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;
 }
 
-template <class Body, class T, class FP, int NS>
-inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+template <class Body, class T, int NIN, class FP, int NS>
+inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out, hipStream_t stream,
                          int chunk_req) {
-  if (!march2_eligible<T, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
+  if (!march2_eligible<T, NIN, FP>(g, in, out)) return NEPTUNE_HIP_EUNSUPPORTED;
   if (geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;   // pure copies: leave to the plain path
   // window shape: NEPTUNE_HIP_MARCH2 = 0..3 picks one for measurements (tools/twostep_bench.py)
   static const int shape = [] { const char* e = getenv("NEPTUNE_HIP_MARCH2"); return e ? atoi(e) : 0; }();
-  if constexpr (NS == 2) {
+  constexpr bool wide = FP::R0 > 1 || FP::R1 > 1 || FP::R2 > 1;
+  if constexpr (wide) {
+    // radius 2 (13-point 4th-order operators): five planes per ring and two halo rows per side and stage; two applies per
+    // pass only -- three rings of five planes do not fit the registers.  Eight waves (up to 256 VGPRs each):
+    //   rows per lane x waves   4x8: window 32 rows, keeps 32 - 4 R1   3x8: 24 rows (fewer registers)
+    if constexpr (NS != 2) {
+      return NEPTUNE_HIP_EUNSUPPORTED;
+    } else {
+      switch (shape) {
+        default:
+        case 0: return launch_march2_shape<Body, T, NIN, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+        case 1: return launch_march2_shape<Body, T, NIN, FP, 2, 3, 8, 1>(body, g, in, out, stream, chunk_req);
+        // (2x16 needs 136 VGPRs per wave: a 16-wave workgroup may use 128; 5x8 spills)
+      }
+    }
+  } else if constexpr (NS == 2) {
     // Measured on 1024^3 fp64, 7-point operator, 128-plane chunks, steps/s against one apply per pass (2.82 ms/step),
     // profiles/r02_twostep.txt:  rows per lane x waves  3x16: 1.79x (108 VGPRs)   7x8: 1.81x (228 VGPRs)   6x8: 1.75x
     // 2x16: 1.74x   5x8: 1.75x   4x8: 1.59x   4x16 (spills): 1.51x.  Default: 3x16 -- sixteen waves keep 48 KiB of row
     // loads in flight per CU with registers to spare for bodies heavier than the Laplacian.
     switch (shape) {
       default:
-      case 0: return launch_march2_shape<Body, T, FP, 2, 3, 16, 1>(body, g, in, out, stream, chunk_req);
+      case 0: return launch_march2_shape<Body, T, NIN, FP, 2, 3, 16, 1>(body, g, in, out, stream, chunk_req);
 #if NEPTUNE_HIP_FULL_VARIANTS
-      case 1: return launch_march2_shape<Body, T, FP, 2, 7, 8, 1>(body, g, in, out, stream, chunk_req);
-      case 2: return launch_march2_shape<Body, T, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
-      case 3: return launch_march2_shape<Body, T, FP, 2, 2, 16, 1>(body, g, in, out, stream, chunk_req);
+      case 1: return launch_march2_shape<Body, T, NIN, FP, 2, 7, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 2: return launch_march2_shape<Body, T, NIN, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 3: return launch_march2_shape<Body, T, NIN, FP, 2, 2, 16, 1>(body, g, in, out, stream, chunk_req);
 #endif
     }
   } else {
     // three applies per pass: three rings of three planes per lane
     switch (shape) {
       default:
-      case 0: return launch_march2_shape<Body, T, FP, 3, 3, 12, 1>(body, g, in, out, stream, chunk_req);
+      case 0: return launch_march2_shape<Body, T, NIN, FP, 3, 3, 12, 1>(body, g, in, out, stream, chunk_req);
 #if NEPTUNE_HIP_FULL_VARIANTS
-      case 1: return launch_march2_shape<Body, T, FP, 3, 2, 12, 1>(body, g, in, out, stream, chunk_req);
-      case 2: return launch_march2_shape<Body, T, FP, 3, 4, 8, 1>(body, g, in, out, stream, chunk_req);
-      case 3: return launch_march2_shape<Body, T, FP, 3, 5, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 1: return launch_march2_shape<Body, T, NIN, FP, 3, 2, 12, 1>(body, g, in, out, stream, chunk_req);
+      case 2: return launch_march2_shape<Body, T, NIN, FP, 3, 4, 8, 1>(body, g, in, out, stream, chunk_req);
+      case 3: return launch_march2_shape<Body, T, NIN, FP, 3, 5, 8, 1>(body, g, in, out, stream, chunk_req);
 #endif
     }
   }
@@ -437,13 +511,16 @@ inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, co
 template <class Body, class T, int RANK, int NIN, class FP, int NS = 2>
 inline int launch_apply_chain(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out,
                               hipStream_t stream, const neptune_hip_launch_cfg_t* cfg) {
-  if constexpr (RANK == 3 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 1 && FP::R2 == 1 && !FP::BOX &&
-                FP::HALO_MASK == 1u) {
-    if (!g || !in || !in[0] || !out) return NEPTUNE_HIP_EINVAL;
+  if constexpr (RANK == 3 && march2_footprint<FP>()) {
+    // rank 3: stars of input 0 up to radius 2 per axis; inputs 1.. (read at the centre only: FP::HALO_MASK == 1) are the same
+    // field at every stage
+    if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
+    for (int k = 0; k < NIN; ++k)
+      if (!in[k]) return NEPTUNE_HIP_EINVAL;
     if (cfg && cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_EUNSUPPORTED;
     const int rc = geom_validate(g);
     if (rc != NEPTUNE_HIP_OK) return rc;
-    return launch_march2<Body, T, FP, NS>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
+    return launch_march2<Body, T, NIN, FP, NS>(body, g, in, out, stream, cfg ? cfg->chunk : 0);
   } else if constexpr (RANK == 2 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX &&
                        FP::HALO_MASK == 1u) {
     if (!g || !in || !in[0] || !out) return NEPTUNE_HIP_EINVAL;

@@ -457,8 +457,10 @@ int neptune_hip_apply2_builtin(int body, const neptune_hip_apply_geom_t* g, cons
 namespace {
 // `applies` (2 or 3) chained applies in one launch when the body and the geometry allow it (else NEPTUNE_HIP_EUNSUPPORTED)
 int loop_launch_chain(const LoopKey& k, int applies, int from, int to) {
-  if (k.g.num_inputs != 1) return NEPTUNE_HIP_EUNSUPPORTED;
-  const void* ins[1] = {k.fields[from]};
+  // inputs 1.. (centre-only inputs of a lowered apply: the same field at every stage) ride along unchanged
+  const void* ins[NEPTUNE_HIP_MAX_INPUTS];
+  for (int i = 0; i < k.g.num_inputs; ++i) ins[i] = k.in[i];
+  ins[0] = k.fields[from];
   const neptune_hip_launch_cfg_t* cfg = (k.cfg.kernel || k.cfg.variant >= 0 || k.cfg.chunk || k.cfg.flags) ? &k.cfg : nullptr;
   if (cfg && (cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT || cfg->variant >= 0)) return NEPTUNE_HIP_EUNSUPPORTED;  // an explicit tile was asked for
   if (k.fn) {

@@ -217,6 +217,80 @@ def test_chains_of_a_generated_body_with_an_index_argument(nh, elem, tmp_path, m
         assert helpers.bits_equal(out.numpy(), chain[applies]), f"{applies} applies\n" + helpers.mismatch_report(out.numpy(), chain[applies])
 
 
+WIDE_CASES = {
+    # name: (element, shape, inputs, radii per axis of input 0)
+    "radius2_f64": ("f64", (11, 60, 272), 1, (2, 2, 2)),
+    "radius2_f32": ("f32", (9, 44, 528), 1, (2, 2, 2)),
+    "radii_1_2_1_f64": ("f64", (8, 40, 264), 1, (1, 2, 1)),
+    "radii_2_1_2_f64": ("f64", (12, 36, 256), 1, (2, 1, 2)),
+    "radius1_with_coefficient_field": ("f64", (9, 50, 272), 2, (1, 1, 1)),
+    "radius2_with_two_coefficient_fields_f32": ("f32", (10, 40, 512), 3, (2, 2, 2)),
+}
+
+
+@pytest.mark.parametrize("name", list(WIDE_CASES))
+def test_chains_beyond_the_7_point_family(nh, name, tmp_path, monkeypatch):
+    """round 3: the chain kernel takes star footprints of input 0 up to radius 2 per axis (13-point 4th-order operators:
+    two applies per pass) and further inputs read at the centre only (coefficient fields, the same at every stage):
+    out = A(A(u; c); c) in one launch == two launches == the oracle's chained applies, bit for bit; chunk seams, window
+    seams along J and K in both element types; a step loop over the pair entry"""
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    import test_multihalo_gpu as mh
+    from neptune_hip import lowering
+    elem, shape, nin, rad = WIDE_CASES[name]
+    acc = [(0, (0, 0, 0))]
+    for d in range(3):
+        for sdist in range(1, rad[d] + 1):
+            for sign in (-1, 1):
+                o = [0, 0, 0]
+                o[d] = sign * sdist
+                acc.append((0, tuple(o)))
+    acc += [(k, (0, 0, 0)) for k in range(1, nin)]
+    lb, ub = list(rad), [n - r for n, r in zip(shape, rad)]
+    text = mh.module_text(shape, elem, nin, acc, lb, ub)
+    mod = lowering.compile_module(text)
+    entry = mod.geom_entry("resid")
+    npdt = np.float32 if elem == "f32" else np.float64
+    u = (helpers.hash_field(shape, npdt, seed=13) * npdt(0.01)).astype(npdt)
+    coef = [(helpers.hash_field(shape, npdt, seed=20 + k) * npdt(0.01)).astype(npdt) for k in range(1, nin)]
+    m = helpers.oracle.Module.parse(text)
+    chain = [u]
+    for _ in range(4):
+        o = np.zeros(shape, npdt)
+        m.call("entry", o, chain[-1], *coef)
+        chain.append(o)
+    bounds = (lb, ub)
+    fin = nh.fields.DeviceField.from_numpy(u)
+    fco = [nh.fields.DeviceField.from_numpy(c) for c in coef]
+    out = nh.fields.DeviceField.empty_like(fin)
+    import ctypes as C
+    g = nh.apply.geom_for([fin] + fco, out, bounds)
+    ins = nh.apply._in_array([fin] + fco)
+    wide = max(rad) > 1
+    for chunk in (0, 3):
+        out.tensor.fill_(float("nan"))
+        cfg = nh.apply.make_cfg(chunk=chunk)
+        assert entry.fn2(C.byref(g), ins, out.ptr, None, C.byref(cfg)) == 0
+        nh.torch.cuda.synchronize()
+        assert helpers.bits_equal(out.numpy(), chain[2]), f"{name} chunk {chunk}\n" + helpers.mismatch_report(out.numpy(), chain[2])
+    # three applies per pass: the radius-1 footprints take it, radius 2 declines (three rings of five planes do not fit)
+    rc3 = entry.fn3(C.byref(g), ins, out.ptr, None, None)
+    if wide:
+        assert rc3 == nh.capi.EUNSUPPORTED
+    else:
+        assert rc3 == 0
+        nh.torch.cuda.synchronize()
+        assert helpers.bits_equal(out.numpy(), chain[3]), helpers.mismatch_report(out.numpy(), chain[3])
+    # a step loop: the coefficient fields ride along as the fixed inputs 1..
+    with monkeypatch.context() as mp:
+        mp.setenv("NEPTUNE_HIP_CHAIN_MIN_CELLS", "0")
+        a = nh.fields.DeviceField.from_numpy(u)
+        b = nh.fields.DeviceField.empty_like(a)
+        res = nh.apply.step_loop(entry, a, b, bounds, 4, others=fco)
+        nh.torch.cuda.synchronize()
+        assert helpers.bits_equal(res.numpy(), chain[4]), helpers.mismatch_report(res.numpy(), chain[4])
+
+
 CASES_2D = [
     ((40, 256), None, None),
     ((300, 376), None, None),                          # four column windows, chunk seams along the rows
