@@ -470,10 +470,12 @@ inline int launch_march2(const Body& body, const neptune_hip_apply_geom_t* g, co
     if constexpr (NS != 2) {
       return NEPTUNE_HIP_EUNSUPPORTED;
     } else {
+      // measured (512^3 fp64, profiles/r03_chain_wide.txt): 13-point Laplacian 3x8: 1.12x the steps per second of one apply per
+      // launch, 4x8 (236 VGPRs): 0.99x; with a coefficient field 3x8: 1.18x, 4x8 spills: 0.45x
       switch (shape) {
         default:
-        case 0: return launch_march2_shape<Body, T, NIN, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
-        case 1: return launch_march2_shape<Body, T, NIN, FP, 2, 3, 8, 1>(body, g, in, out, stream, chunk_req);
+        case 0: return launch_march2_shape<Body, T, NIN, FP, 2, 3, 8, 1>(body, g, in, out, stream, chunk_req);
+        case 1: return launch_march2_shape<Body, T, NIN, FP, 2, 4, 8, 1>(body, g, in, out, stream, chunk_req);
         // (2x16 needs 136 VGPRs per wave: a 16-wave workgroup may use 128; 5x8 spills)
       }
     }

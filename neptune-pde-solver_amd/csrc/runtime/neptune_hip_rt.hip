@@ -606,13 +606,59 @@ int neptune_hip_step_loop_chain(neptune_hip_apply_fn fn, neptune_hip_apply_fn fn
   const char* min_cells_env = getenv("NEPTUNE_HIP_CHAIN_MIN_CELLS");
   const int64_t min_cells = min_cells_env ? atoll(min_cells_env) : (int64_t)4000000;
   const bool chain_ok = cells >= min_cells && !getenv("NEPTUNE_HIP_NO_PAIRS");
-  if (steps >= 3 && chain_ok && !getenv("NEPTUNE_HIP_NO_TRIPLES")) {
+  // ... and whether chaining pays for THIS body is measured, once per (entry, geometry) and process: a Laplacian gains
+  // 1.7-2.4x, a 13-point operator 1.1x on its 3x8 window, a body heavy enough to be bound by its arithmetic loses (the
+  // windows overlap: every stage computes 1.3-1.8x the cells it keeps).  Each grouping the entry offers runs once to warm
+  // and twice under HIP events, from fields[0] into fields[1] -- exactly what the loop's first step overwrites anyway.
+  // Skipped for short loops, under stream capture and with NEPTUNE_HIP_TUNE=0 (then: the largest grouping offered).
+  int best = 3;
+  if (chain_ok && steps >= 8 && tune_mode() != 0) {
+    struct Choice { neptune_hip_apply_fn fn, fn2, fn3; int body; neptune_hip_apply_geom_t g; int best; };
+    static std::vector<Choice> choices;
+    static std::mutex cmu;
+    bool known = false;
+    {
+      std::lock_guard<std::mutex> lk(cmu);
+      for (const Choice& c : choices)
+        if (c.fn == key.fn && c.fn2 == key.fn2 && c.fn3 == key.fn3 && c.body == key.body && memcmp(&c.g, &key.g, sizeof(key.g)) == 0) {
+          best = c.best;
+          known = true;
+        }
+    }
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(key.stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (!known && cs == hipStreamCaptureStatusNone) {
+      hipEvent_t e0, e1;
+      NEPTUNE_HIP_CHECK(hipEventCreate(&e0));
+      NEPTUNE_HIP_CHECK(hipEventCreate(&e1));
+      double best_ms = -1;
+      for (int applies = 1; applies <= 3; ++applies) {
+        if (applies == 3 && getenv("NEPTUNE_HIP_NO_TRIPLES")) continue;
+        auto one = [&] { return applies == 1 ? loop_launch(key, 0, 1) : loop_launch_chain(key, applies, 0, 1); };
+        if (one() != NEPTUNE_HIP_OK) continue;              // a grouping this entry / geometry does not offer
+        NEPTUNE_HIP_CHECK(hipEventRecord(e0, key.stream));
+        (void)one();
+        (void)one();
+        NEPTUNE_HIP_CHECK(hipEventRecord(e1, key.stream));
+        NEPTUNE_HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double per_step = ms / (2.0 * applies);
+        if (best_ms < 0 || per_step < 0.97 * best_ms) { best_ms = per_step; best = applies; }   // a larger grouping must win by 3 %
+      }
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+      std::lock_guard<std::mutex> lk(cmu);
+      choices.push_back({key.fn, key.fn2, key.fn3, key.body, key.g, best});
+    }
+  }
+  if (steps >= 3 && chain_ok && best >= 3 && !getenv("NEPTUNE_HIP_NO_TRIPLES")) {
     const int64_t triples = steps / 3;
     const int rc3 = run_launches(3, triples, 0);
     if (rc3 == NEPTUNE_HIP_OK) return finish(run_launches(1, steps - 3 * triples, (int)(triples % 2)));
     if (rc3 != NEPTUNE_HIP_EUNSUPPORTED) return finish(rc3);
   }
-  if (steps >= 4 && chain_ok) {
+  if (steps >= 4 && chain_ok && best >= 2) {
     const int64_t pairs = (steps / 2) & ~(int64_t)1;
     const int rc2 = run_launches(2, pairs, 0);
     if (rc2 == NEPTUNE_HIP_OK) return finish(run_launches(1, steps - 2 * pairs, 0));

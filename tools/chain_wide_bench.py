@@ -20,13 +20,54 @@ def main():
     lib = _capi.load()
     lib.neptune_hip_init(0)
     sizes = [int(x) for x in sys.argv[1:] if x.isdigit()] or [512]
+    fix13 = (REPO / "tests/mlir_tests/conversion_tests/apply-3d-13pt.mlir").read_text()
     for n in sizes:
         shape = (n, n, n)
-        for name, nin, r in (("13-point (radius 2)", 1, 2), ("7-point + coefficient field", 2, 1), ("13-point + coefficient field", 2, 2)):
+        # the committed 13-point fixture's body at this size; a variable-coefficient 7-point diffusion operator
+        # u + c * lap(u) (c read at the centre); and generated weighted stars (one multiply per tap, an index term)
+        lap13 = fix13.replace("ub = [20, 18, 256]", f"ub = [{n}, {n}, {n}]").replace("ub = [18, 16, 254]", f"ub = [{n - 2}, {n - 2}, {n - 2}]")
+        varc = f"""
+#l = #neptune_ir.location<"cell">
+#b = #neptune_ir.bounds<lb = [0, 0, 0], ub = [{n}, {n}, {n}]>
+!t = !neptune_ir.temp<element = f64, bounds = #b, location = #l>
+module {{
+  neptune_ir.nonlinear_opdef @resid : (!t, !t) -> !t {{
+  ^bb0(%u: !t, %c: !t):
+    %r = neptune_ir.apply(%u, %c) attributes {{bounds = #neptune_ir.bounds<lb = [1, 1, 1], ub = [{n - 1}, {n - 1}, {n - 1}]>}} : (!t, !t) -> !t {{
+      ^bb0(%i: index, %j: index, %k: index, %a: !t, %ca: !t):
+        %c0 = neptune_ir.access %a[0, 0, 0] : !t -> f64
+        %xm = neptune_ir.access %a[-1, 0, 0] : !t -> f64
+        %xp = neptune_ir.access %a[1, 0, 0] : !t -> f64
+        %ym = neptune_ir.access %a[0, -1, 0] : !t -> f64
+        %yp = neptune_ir.access %a[0, 1, 0] : !t -> f64
+        %zm = neptune_ir.access %a[0, 0, -1] : !t -> f64
+        %zp = neptune_ir.access %a[0, 0, 1] : !t -> f64
+        %kc = neptune_ir.access %ca[0, 0, 0] : !t -> f64
+        %six = arith.constant 6.0 : f64
+        %t0 = arith.addf %xm, %xp : f64
+        %t1 = arith.addf %t0, %ym : f64
+        %t2 = arith.addf %t1, %yp : f64
+        %t3 = arith.addf %t2, %zm : f64
+        %t4 = arith.addf %t3, %zp : f64
+        %t5 = arith.mulf %six, %c0 : f64
+        %t6 = arith.subf %t4, %t5 : f64
+        %t7 = arith.mulf %kc, %t6 : f64
+        %o = arith.addf %c0, %t7 : f64
+        neptune_ir.yield %o : f64
+    }}
+    neptune_ir.return %r : !t
+  }}
+}}
+"""
+        cases = [("13-point 4th-order Laplacian (the committed fixture's body)", 1, 2, lap13, "lap13"),
+                 ("7-point diffusion with a coefficient field", 2, 1, varc, "resid"),
+                 ("generated 13-tap weighted star + index term", 1, 2, None, "resid"),
+                 ("generated 13-tap weighted star + coefficient field", 2, 2, None, "resid")]
+        for name, nin, r, text, sym in cases:
             acc = [(0, o) for o in mh.star(3, r)] + [(k, (0, 0, 0)) for k in range(1, nin)]
             bounds = ([r] * 3, [n - r] * 3)
-            mod = lowering.compile_module(mh.module_text(shape, "f64", nin, acc, bounds[0], bounds[1]))
-            entry = mod.geom_entry("resid")
+            mod = lowering.compile_module(text if text is not None else mh.module_text(shape, "f64", nin, acc, bounds[0], bounds[1]))
+            entry = mod.geom_entry(sym)
             a = fields.DeviceField.hashed(shape, _capi.F64, seed=5)
             a.tensor.mul_(1e-3)
             b = fields.DeviceField.empty_like(a)
