@@ -433,7 +433,10 @@ def main():
     }
     halo_group, comms, ops, verdicts, transport, chosen = None, {}, {}, {}, ("none" if world == 1 else None), None
     if world > 1 and emu is None:
-        wanted = {"auto": ["rccl-c", "peer-c", "torch"], "c-abi": ["rccl-c"], "peer": ["peer-c"], "torch": ["torch"]}[args.halo_transport]
+        # order: the peer transport first (every wait of it is bounded: a failure costs the candidate, not the run), then
+        # torch's point-to-point ops (the communicator the first all_reduce already proved), then a second RCCL communicator
+        # of our own (ncclCommInitRank beside torch's: the one stage that could only be ended by the watchdog)
+        wanted = {"auto": ["peer-c", "torch", "rccl-c"], "c-abi": ["rccl-c"], "peer": ["peer-c"], "torch": ["torch"]}[args.halo_transport]
         if args.rehearse_on_one_gpu:       # two processes cannot share a device under RCCL; the peer transport can
             wanted = [w for w in wanted if w == "peer-c"]
         for name in wanted:

@@ -206,7 +206,10 @@ struct MarchVariant {
   X(40, 4, 4, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj4_wj4_wk1_pf1") \
   X(41, 2, 12, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj2_wj12_wk1_pf1") \
   X(42, 2, 16, 1, true, true, 1, false, true, false, true, 1, true, "pln_rj2_wj16_wk1_pf1") \
-  X(43, 1, 16, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj1_wj16_wk1_pf2")
+  X(43, 1, 16, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj1_wj16_wk1_pf2") \
+  X(44, 2, 16, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj2_wj16_wk1_pf2") \
+  X(45, 2, 16, 1, true, true, 3, false, true, false, true, 1, true, "pln_rj2_wj16_wk1_pf3") \
+  X(46, 3, 8, 1, true, true, 2, false, true, false, true, 1, true, "pln_rj3_wj8_wk1_pf2")
 #define NEPTUNE_MARCH2_VARIANTS(X)                \
   NEPTUNE_MARCH2_DEFAULT(X)                                      \
   X(3, 1, 1, 4, true, true, 2, false, false, false, false, 1, false, "wk4_pf2")  \

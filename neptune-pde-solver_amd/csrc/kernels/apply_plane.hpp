@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   // 10 slots keep the rotation, slots NPR.. being the planes in flight then.
   constexpr int RR = R0 > 1 ? R0 : 1, NPR = 2 * RR + 1;
   constexpr int NS = NPR + PF;
-  constexpr bool PHASED = NS <= 10;
+  constexpr bool PHASED = NS <= 11;
   constexpr int UNROLL = PHASED ? NS : PF;
   V ring[NH][NS][RJ];
   V jh[NHWX];   // my halo-row units (and kh: the halo cells beside my rows) of plane i+1, in flight while step i-1 computes
