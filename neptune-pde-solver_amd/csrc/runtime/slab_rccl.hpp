@@ -146,9 +146,13 @@ inline int peer_exchange_many(Comm* c, void* const* fields, const size_t* plane_
   uint64_t* sig_arrived[2] = {nullptr, nullptr};
   const uint64_t* wait_free[2] = {nullptr, nullptr};
   const uint64_t* wait_arrived[2] = {nullptr, nullptr};
+  // which side of the NEIGHBOUR my pushes land on: its opposite side -- except in a one-sided loop-back (an emulated edge
+  // rank: the neighbour is this rank itself, which has no ghost planes on the opposite side), where the planes come back
+  // into my own ghost planes of the same side, as an RCCL loop-back would deliver them
+  auto landing = [&](int side) { return (peers[side] == s->rank && r[1 - side] == 0) ? side : 1 - side; };
   for (int side = 0; side < 2; ++side) {
     if (r[side] == 0) continue;
-    const int opp = 1 - side;
+    const int opp = landing(side);
     sig_free[side] = &mail(peers[side])->peer_free[opp];      // I am the neighbour's `opp`-side neighbour
     sig_arrived[side] = &mail(peers[side])->arrived[opp];
     wait_free[side] = &mail(s->rank)->peer_free[side];
@@ -158,7 +162,7 @@ inline int peer_exchange_many(Comm* c, void* const* fields, const size_t* plane_
   // 3. the pushes: my edge planes -> the neighbour's ghost planes (its descriptor exists once it has called this exchange)
   for (int side = 0; side < 2; ++side) {
     if (r[side] == 0) continue;
-    const int opp = 1 - side;
+    const int opp = landing(side);
     peer::RankShm& nb = s->shm->ranks[peers[side]];
     for (int f = 0; f < nfields; ++f) {
       const uint64_t seq = s->seq[side] + 1 + (uint64_t)f;

@@ -84,6 +84,31 @@ def test_halo_exchange_loopback_fills_the_ghost_planes(nh, radius):
         assert helpers.bits_equal(t.cpu().numpy(), loopback(b, lo, hi, radius, nh.transport))
 
 
+@pytest.mark.parametrize("side", ["lo", "hi"])
+def test_one_sided_loopback_of_an_edge_rank(nh, side):
+    """an edge rank of the decomposition has ghost planes on one side only; as a loop-back (bench.py --emulate-rank 0/W) both
+    transports return the rank's own edge planes of that side into its ghost planes"""
+    r = 1
+    own = 10
+    glb, gub = (0, 0, 0), (own + 30, 6, 128)
+    sl = (nh.slab.Slab(rank=0, world=1, radius=r, glb=glb, gub=gub, start=0, stop=own, r_lo=0, r_hi=r) if side == "hi" else
+          nh.slab.Slab(rank=0, world=1, radius=r, glb=glb, gub=gub, start=20, stop=20 + own, r_lo=r, r_hi=0))
+    u = helpers.hash_field(sl.local_shape, np.float64, seed=37)
+    lo, hi = sl.owned_planes()
+    u[:lo] = np.nan
+    u[hi:] = np.nan
+    t = nh.torch.from_numpy(u.copy()).cuda()
+    for _ in range(3):                        # the handshake counters advance on one side only
+        nh.comm.exchange(sl, t, peer_lo=0, peer_hi=0)
+    nh.torch.cuda.synchronize()
+    want = u.copy()
+    if side == "hi":
+        want[hi:] = u[hi - r:hi]
+    else:
+        want[:lo] = u[lo:lo + r]
+    assert helpers.bits_equal(t.cpu().numpy(), want), helpers.mismatch_report(t.cpu().numpy(), want)
+
+
 def test_halo_exchange_rejects_bad_requests(nh):
     t = nh.torch.zeros((4, 2, 64), dtype=nh.torch.float64, device="cuda")
     lib = nh.lib
