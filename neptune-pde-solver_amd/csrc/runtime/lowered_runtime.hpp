@@ -558,8 +558,8 @@ inline void run_store(Scope& sc, const Val& src, const Val& dst, const Box* boun
 
 // footprint / radius table of a two-input pointwise apply (time_advance's axpy step)
 using PointwiseFP = Footprint<-1, 0, 0, 0, false, true>;
-static const int32_t kPointwiseRadius2[NEPTUNE_HIP_MAX_INPUTS][NEPTUNE_HIP_MAX_RANK] = {
-    {0, 0, 0}, {0, 0, 0}, {-1, -1, -1}, {-1, -1, -1}};
+static const neptune_hip::Reach kPointwiseRadius2 = {{{0, 0, 0}, {0, 0, 0}, {1, 1, 1}, {1, 1, 1}},        // two inputs read at the centre,
+                                                    {{0, 0, 0}, {0, 0, 0}, {-1, -1, -1}, {-1, -1, -1}}};  // the others not at all (hi < lo)
 
 // neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
 // slab mode: this rank's partial sum over its owned planes (the caller adds the ranks' results)

@@ -579,3 +579,21 @@ def test_as_tensor_and_from_tensor_are_casts_of_the_same_buffer():
     want = x.copy()
     want[1:7, 1:127] = x[0:6, 1:127] + x[2:8, 1:127]
     assert helpers.bits_equal(np.asarray(got), want)
+
+
+def test_every_committed_module_cross_compiles_for_gfx950(tmp_path, monkeypatch):
+    """every .mlir this repository commits (conversion fixtures, time-stepping and nonlinear fixtures, the golden KAT modules)
+    goes through lower + hipcc --offload-arch=gfx950 here, without a GPU: a change of the runtime headers that breaks ANY
+    emitted construct (a fused or unfused time step, a reduce, a rank-4 apply, an outlined function) shows up in the CPU suite
+    instead of at the first GPU run"""
+    import glob
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
+    paths = sorted(glob.glob(str(helpers.REPO / "tests/mlir_tests/**/*.mlir"), recursive=True)) + sorted(glob.glob(str(GOLDEN_DIR / "*.mlir")))
+    assert len(paths) >= 10
+    texts = [Path(f).read_text() for f in paths]
+    helpers.prefetch_modules(texts, workers=6)
+    built = {lowering.module_hash(t) for t in texts}
+    missing = [f for f, t in zip(paths, texts) if not (tmp_path / f"neptune_kernel_{lowering.module_hash(t)}.so").exists()]
+    logs = "".join(p.read_text()[:1500] for p in tmp_path.glob("*.log") if "error" in p.read_text())
+    assert not missing, f"did not compile: {missing}\n{logs}"
+    assert len(built) == len(set(texts))
