@@ -257,7 +257,7 @@ __global__ __launch_bounds__(kWave* WJ, MINW) void neptune_apply_march2(March2Pa
 // of a 2-D explicit scheme (the reference's own time-stepping inputs are 1-D / 2-D) cost one read and one write of the
 // field plus 128/120 in columns and 2 NS rows per chunk.
 struct March2R2Params {
-  const void* in;
+  const void* in[NEPTUNE_HIP_MAX_INPUTS];   // in[0]: the field the applies chain on; in[1..]: centre-only inputs, the same at every stage
   void* out;
   int32_t N0, N1;          // rows, columns
   int32_t plb[2], pub[2];
@@ -267,71 +267,99 @@ struct March2R2Params {
   uint32_t nK;
 };
 
-template <class Body, class T, class FP, int NS, int PF>
+// star footprints of input 0 up to radius 2 along the rows (R0) and the columns (R2); FP::R1 == 0 in rank 2
+template <class FP>
+constexpr bool march2_rank2_footprint() {
+  return FP::MARCH_OK && !FP::BOX && FP::HALO_MASK == 1u && FP::R0 >= 1 && FP::R0 <= 2 && FP::R1 == 0 && FP::R2 >= 1 && FP::R2 <= 2;
+}
+
+template <class Body, class T, int NIN, class FP, int NS, int PF>
 __global__ __launch_bounds__(256) void neptune_apply_march2_rank2(March2R2Params P, Body body) {
   using V = typename Vec16<T>::type;
-  constexpr int VK = 16 / sizeof(T);
-  constexpr int G = 64 / (int)sizeof(T), SPAN = kWave * VK, KEEPK = SPAN - G;
-  static_assert(NS >= 2 && NS <= 3 && (G / 2) % VK == 0 && G / 2 >= NS, "window constants");
-  static_assert(FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u, "radius-1 star of input 0, rank 2");
+  using GM = March2Geom<T, FP, NS>;
+  constexpr int VK = GM::VK, R0 = GM::R0, R2 = GM::R2, NP = 2 * R0 + 1, MK = GM::MK, SPAN = GM::SPAN, KEEPK = GM::KEEPK;
+  static_assert(NS >= 2 && NS <= 3 && march2_rank2_footprint<FP>() && R2 <= VK, "window constants");
+  constexpr int NQ = (NS - 1) * R0 + 1;       // rows of a centre-only input between the first stage's row and the last one's
+  constexpr int NF = NIN > 1 ? NIN - 1 : 1;
   const int lane = threadIdx.x & (kWave - 1);
   const uint32_t gw = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);   // global wave id: column windows fastest
   const uint32_t kt = gw % P.nK, ct = gw / P.nK;
-  const int32_t kw = (int32_t)(kt * KEEPK) - G / 2;
+  const int32_t kw = (int32_t)(kt * KEEPK) - MK;
   const int32_t k0 = kw + lane * VK;
   const int32_t kc = k0 < 0 ? 0 : (k0 > P.N1 - VK ? P.N1 - VK : k0);
   const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
   const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
   if (ib >= ie) return;
-  const T* in = static_cast<const T*>(P.in);
   T* out = static_cast<T*>(P.out);
-  auto load_row = [&](int32_t ip) -> V {
+  auto load_row = [&](int n, int32_t ip) -> V {
     const int32_t ic = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
-    return *reinterpret_cast<const V*>(in + (int64_t)ic * P.N1 + kc);
+    return *reinterpret_cast<const V*>(static_cast<const T*>(P.in[n]) + (int64_t)ic * P.N1 + kc);
   };
   bool in_k[VK];
   static_for<VK>([&](auto ec) { constexpr int e = ec; in_k[e] = (k0 + e) >= P.plb[1] && (k0 + e) < P.pub[1]; });
-  const bool lane_keep = k0 >= kw + G / 2 && k0 < kw + SPAN - G / 2 && k0 >= 0 && k0 < P.N1;
+  const bool lane_keep = k0 >= kw + MK && k0 < kw + SPAN - MK && k0 >= 0 && k0 < P.N1;
 
-  auto stage = [&](const V& lo, const V& ctr, const V& hi, int32_t ip) -> V {
-    V ring[1][3][1] = {{{lo}, {ctr}, {hi}}};
-    T lft[1][1][1][1], rgt[1][1][1][1];
-    V pt[1][1];
-    lft[0][0][0][0] = from_prev<true>(ctr[VK - 1], ctr[0], lane);
-    rgt[0][0][0][0] = from_next<true>(ctr[0], ctr[VK - 1], lane);
+  auto stage = [&](const V(&pl)[NP], const V(&fx)[NF][NQ], auto qc, int32_t ip) -> V {
+    constexpr int q = decltype(qc)::value;
+    V ring[1][NP][1];
+    T lft[1][1][1][R2], rgt[1][1][1][R2];
+    V pt[NIN][1];
+    static_for<NP>([&](auto pc) { constexpr int pp = pc; ring[0][pp][0] = pl[pp]; });
+    static_for<R2>([&](auto xc) {
+      constexpr int x = xc;
+      constexpr int dl = R2 - x, dr = x + 1;
+      lft[0][0][0][x] = from_prev<true>(pl[R0][VK - dl], pl[R0][0], lane);
+      rgt[0][0][0][x] = from_next<true>(pl[R0][dr - 1], pl[R0][VK - 1], lane);
+    });
+    static_for<NIN>([&](auto nc) { constexpr int n = nc; if constexpr (n > 0) pt[n][0] = fx[n - 1][q]; });
     const bool in_i = ip >= P.plb[0] && ip < P.pub[0];
     const int64_t li = (int64_t)ip + P.olb[0];
     V res;
     static_for<VK>([&](auto ec) {
       constexpr int e = ec;
       const int64_t lk = (int64_t)(k0 + e) + P.olb[1];
-      MarchAcc<T, 2, 1, FP, 1, 0, e, false> acc{ring, lft, rgt, pt, li, 0, lk};
+      MarchAcc<T, 2, NIN, FP, 1, 0, e, false> acc{ring, lft, rgt, pt, li, 0, lk};
       const T val = body(acc);
-      res[e] = (in_i && in_k[e]) ? val : OutsideOf<Body, T>::apply(body, ctr[e]);
+      res[e] = (in_i && in_k[e]) ? val : OutsideOf<Body, T>::apply(body, pl[R0][e]);
     });
     return res;
   };
 
-  // ring[k]: the three newest rows of stage input k (k = 0: the field itself); un: rows in flight
-  V ring[NS][3];
+  // ring[k]: the 2 R0 + 1 newest rows of stage input k (k = 0: the field itself); un: rows in flight; fx / fn: the centre-only
+  // inputs' rows between the stages, and in flight
+  V ring[NS][NP];
   V un[PF];
-  const int32_t i0 = ib - 2 * (NS - 1);
-  ring[0][0] = load_row(i0 + NS - 2);
-  ring[0][1] = load_row(i0 + NS - 1);
-  static_for<PF>([&](auto dc) { constexpr int d = dc; un[d] = load_row(i0 + NS + d); });
-  static_for<NS - 1>([&](auto kc2) { constexpr int k = kc2 + 1; ring[k][0] = ring[0][0]; ring[k][1] = ring[0][0]; });
+  V fx[NF][NQ], fn[NF][PF];
+  const int32_t i0 = ib - GM::WARM;
+  static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; ring[0][pp] = load_row(0, i0 + NS * R0 - 2 * R0 + pp); });
+  static_for<PF>([&](auto dc) { constexpr int d = dc; un[d] = load_row(0, i0 + NS * R0 + d); });
+  if constexpr (NIN > 1) {
+    static_for<NIN - 1>([&](auto nc) {
+      constexpr int n = nc;
+      static_for<NQ - 1>([&](auto qc) { constexpr int q = qc; fx[n][q] = load_row(n + 1, i0 + q); });
+      static_for<PF>([&](auto dc) { constexpr int d = dc; fn[n][d] = load_row(n + 1, i0 + NQ - 1 + d); });
+    });
+  }
+  static_for<NS - 1>([&](auto kc2) { constexpr int k = kc2 + 1; static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; ring[k][pp] = ring[0][0]; }); });
   auto step = [&](int32_t i, auto slot_c) {
     constexpr int slot = slot_c;
-    ring[0][2] = un[slot];
-    if (i + NS + PF <= ie + NS - 1) un[slot] = load_row(i + NS + PF);
+    ring[0][NP - 1] = un[slot];
+    if constexpr (NIN > 1) static_for<NIN - 1>([&](auto nc) { constexpr int n = nc; fx[n][NQ - 1] = fn[n][slot]; });
+    if (i + NS * R0 + PF <= ie - 1 + NS * R0) {
+      un[slot] = load_row(0, i + NS * R0 + PF);
+      if constexpr (NIN > 1) static_for<NIN - 1>([&](auto nc) { constexpr int n = nc; fn[n][slot] = load_row(n + 1, i + NQ - 1 + PF); });
+    }
     V w;
     static_for<NS>([&](auto kc2) {
       constexpr int k = kc2;
-      if constexpr (k + 1 < NS) ring[k + 1][2] = stage(ring[k][0], ring[k][1], ring[k][2], i + NS - k - 1);
-      else w = stage(ring[k][0], ring[k][1], ring[k][2], i);
+      constexpr int q = (NS - k - 1) * R0;
+      if constexpr (k + 1 < NS) ring[k + 1][NP - 1] = stage(ring[k], fx, std::integral_constant<int, q>{}, i + q);
+      else w = stage(ring[k], fx, std::integral_constant<int, 0>{}, i);
     });
     if (i >= ib && lane_keep) __builtin_nontemporal_store(w, reinterpret_cast<V*>(out + (int64_t)i * P.N1 + kc));
-    static_for<NS>([&](auto kc2) { constexpr int k = kc2; ring[k][0] = ring[k][1]; ring[k][1] = ring[k][2]; });
+    static_for<NS>([&](auto kc2) { constexpr int k = kc2; static_for<NP - 1>([&](auto pc) { constexpr int pp = pc; ring[k][pp] = ring[k][pp + 1]; }); });
+    if constexpr (NIN > 1)
+      static_for<NIN - 1>([&](auto nc) { constexpr int n = nc; static_for<NQ - 1>([&](auto qc) { constexpr int q = qc; fx[n][q] = fx[n][q + 1]; }); });
   };
   for (int32_t i = i0; i < ie; i += PF) {
     static_for<PF>([&](auto phc) {
@@ -341,29 +369,34 @@ __global__ __launch_bounds__(256) void neptune_apply_march2_rank2(March2R2Params
   }
 }
 
-template <class T, class FP>
-inline bool march2_rank2_eligible(const neptune_hip_apply_geom_t* g, const void* in, const void* out) {
+template <class T, int NIN, class FP>
+inline bool march2_rank2_eligible(const neptune_hip_apply_geom_t* g, const void* const* in, const void* out) {
   constexpr int G = 64 / (int)sizeof(T);
-  if (!g || g->rank != 2 || g->num_inputs != 1) return false;
-  if (!(FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX && FP::HALO_MASK == 1u)) return false;
+  if (!g || g->rank != 2 || g->num_inputs != NIN) return false;
+  if (!march2_rank2_footprint<FP>()) return false;
   int64_t n[2];
+  const int r[2] = {FP::R0, FP::R2};
   for (int d = 0; d < 2; ++d) {
     n[d] = g->out_ub[d] - g->out_lb[d];
-    if (g->in_lb[0][d] != g->out_lb[d] || g->in_ub[0][d] != g->out_ub[d]) return false;
-    if (g->lb[d] < g->ub[d] && (g->lb[d] - 1 < g->out_lb[d] || g->ub[d] + 1 > g->out_ub[d])) return false;
+    for (int k = 0; k < NIN; ++k)
+      if (g->in_lb[k][d] != g->out_lb[d] || g->in_ub[k][d] != g->out_ub[d]) return false;
+    if (g->lb[d] < g->ub[d] && (g->lb[d] - r[d] < g->out_lb[d] || g->ub[d] + r[d] > g->out_ub[d])) return false;
   }
   if (g->region_lb[1] != 0 || g->region_ub[1] != n[1]) return false;
   if (n[1] % G != 0 || n[1] < 2 * G || n[0] < 1 || n[0] >= 0x7fffffffLL || n[1] >= 0x7fffffffLL) return false;
-  return (uintptr_t)in % 64 == 0 && (uintptr_t)out % 64 == 0;
+  if ((uintptr_t)out % 64 != 0) return false;
+  for (int k = 0; k < NIN; ++k)
+    if (!in[k] || (uintptr_t)in[k] % 64 != 0) return false;
+  return true;
 }
 
-template <class Body, class T, class FP, int NS>
-inline int launch_march2_rank2(const Body& body, const neptune_hip_apply_geom_t* g, const void* in, void* out, hipStream_t stream,
+template <class Body, class T, int NIN, class FP, int NS>
+inline int launch_march2_rank2(const Body& body, const neptune_hip_apply_geom_t* g, const void* const* in, void* out, hipStream_t stream,
                                int chunk_req) {
-  if (!march2_rank2_eligible<T, FP>(g, in, out) || geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;
-  constexpr int VK = 16 / (int)sizeof(T), G = 64 / (int)sizeof(T), KEEPK = kWave * VK - G, PF = 4;
+  if (!march2_rank2_eligible<T, NIN, FP>(g, in, out) || geom_bounds_empty(g)) return NEPTUNE_HIP_EUNSUPPORTED;
+  constexpr int KEEPK = March2Geom<T, FP, NS>::KEEPK, PF = 4;
   March2R2Params P{};
-  P.in = in;
+  for (int k = 0; k < NIN; ++k) P.in[k] = in[k];
   P.out = out;
   P.N0 = (int32_t)(g->out_ub[0] - g->out_lb[0]);
   P.N1 = (int32_t)(g->out_ub[1] - g->out_lb[1]);
@@ -378,14 +411,14 @@ inline int launch_march2_rank2(const Body& body, const neptune_hip_apply_geom_t*
   P.nK = (uint32_t)((P.N1 + KEEPK - 1) / KEEPK);
   const int64_t rows = P.rI1 - P.rI0;
   int64_t chunk = chunk_req > 0 ? chunk_req : 256;
-  // enough waves for the chip (256 CUs x 32 waves), but never chunks so short that the 2 NS warm-up rows dominate
+  // enough waves for the chip (256 CUs x 32 waves), but never chunks so short that the warm-up rows dominate
   while (chunk_req <= 0 && chunk > 32 && (int64_t)P.nK * ((rows + chunk - 1) / chunk) < 8192) chunk /= 2;
   if (chunk > rows) chunk = rows;
   P.chunk = (int32_t)chunk;
   const int64_t waves = (int64_t)P.nK * ((rows + chunk - 1) / chunk);
   const int64_t blocks = (waves + 3) / 4;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return NEPTUNE_HIP_EUNSUPPORTED;
-  hipLaunchKernelGGL((neptune_apply_march2_rank2<Body, T, FP, NS, PF>), dim3((uint32_t)blocks), dim3(256), 0, stream, P, body);
+  hipLaunchKernelGGL((neptune_apply_march2_rank2<Body, T, NIN, FP, NS, PF>), dim3((uint32_t)blocks), dim3(256), 0, stream, P, body);
   NEPTUNE_HIP_CHECK(hipGetLastError());
   return NEPTUNE_HIP_OK;
 }
@@ -523,13 +556,16 @@ inline int launch_apply_chain(const Body& body, const neptune_hip_apply_geom_t* 
     const int rc = geom_validate(g);
     if (rc != NEPTUNE_HIP_OK) return rc;
     return launch_march2<Body, T, NIN, FP, NS>(body, g, in, out, stream, cfg ? cfg->chunk : 0);
-  } else if constexpr (RANK == 2 && NIN == 1 && FP::MARCH_OK && FP::R0 == 1 && FP::R1 == 0 && FP::R2 == 1 && !FP::BOX &&
-                       FP::HALO_MASK == 1u) {
-    if (!g || !in || !in[0] || !out) return NEPTUNE_HIP_EINVAL;
+  } else if constexpr (RANK == 2 && march2_rank2_footprint<FP>()) {
+    // rank 2: stars of input 0 up to radius 2 along rows and columns (5- and 9-point operators), centre-only further inputs
+    if (!g || !in || !out) return NEPTUNE_HIP_EINVAL;
+    for (int k = 0; k < NIN; ++k)
+      if (!in[k]) return NEPTUNE_HIP_EINVAL;
     if (cfg && cfg->kernel == NEPTUNE_HIP_KERNEL_DIRECT) return NEPTUNE_HIP_EUNSUPPORTED;
     const int rc = geom_validate(g);
     if (rc != NEPTUNE_HIP_OK) return rc;
-    return launch_march2_rank2<Body, T, FP, NS>(body, g, in[0], out, stream, cfg ? cfg->chunk : 0);
+    // (three rings of five rows: 60 VGPRs in fp64 -- fits, unlike rank 3)
+    return launch_march2_rank2<Body, T, NIN, FP, NS>(body, g, in, out, stream, cfg ? cfg->chunk : 0);
   } else {
     return NEPTUNE_HIP_EUNSUPPORTED;
   }

@@ -225,29 +225,57 @@ WIDE_CASES = {
     "radii_2_1_2_f64": ("f64", (12, 36, 256), 1, (2, 1, 2)),
     "radius1_with_coefficient_field": ("f64", (9, 50, 272), 2, (1, 1, 1)),
     "radius2_with_two_coefficient_fields_f32": ("f32", (10, 40, 512), 3, (2, 2, 2)),
+    # rank 2 (rows marched, no J axis): 9-point stars, unequal radii, coefficient fields; three applies per pass fit at radius 2 too
+    "radius2_2d_f64": ("f64", (300, 376), 1, (2, 2)),
+    "radii_1_2_2d_f32": ("f32", (200, 528), 1, (1, 2)),
+    "radius1_2d_with_coefficient_field": ("f64", (150, 264), 2, (1, 1)),
+    "radius2_2d_with_two_coefficient_fields_f32": ("f32", (120, 512), 3, (2, 2)),
 }
 
 
+def wide_case_text(name):
+    import test_multihalo_gpu as mh
+    elem, shape, nin, rad = WIDE_CASES[name]
+    rank = len(shape)
+    acc = [(0, (0,) * rank)]
+    for d in range(rank):
+        for sdist in range(1, rad[d] + 1):
+            for sign in (-1, 1):
+                o = [0] * rank
+                o[d] = sign * sdist
+                acc.append((0, tuple(o)))
+    acc += [(k, (0,) * rank) for k in range(1, nin)]
+    lb, ub = list(rad), [n - r for n, r in zip(shape, rad)]
+    return mh.module_text(shape, elem, nin, acc, lb, ub), lb, ub
+
+
+@pytest.fixture(scope="module")
+def wide_cache(tmp_path_factory):
+    """the six modules of the wide-chain cases, compiled side by side before the first of them runs"""
+    import os
+    d = tmp_path_factory.mktemp("neptune_cache_wide_chains")
+    saved = os.environ.get("NEPTUNE_CACHE_DIR")
+    os.environ["NEPTUNE_CACHE_DIR"] = str(d)
+    try:
+        helpers.prefetch_modules([wide_case_text(n)[0] for n in WIDE_CASES])
+    finally:
+        if saved is None:
+            os.environ.pop("NEPTUNE_CACHE_DIR", None)
+        else:
+            os.environ["NEPTUNE_CACHE_DIR"] = saved
+    return d
+
+
 @pytest.mark.parametrize("name", list(WIDE_CASES))
-def test_chains_beyond_the_7_point_family(nh, name, tmp_path, monkeypatch):
+def test_chains_beyond_the_7_point_family(nh, name, wide_cache, monkeypatch):
     """round 3: the chain kernel takes star footprints of input 0 up to radius 2 per axis (13-point 4th-order operators:
     two applies per pass) and further inputs read at the centre only (coefficient fields, the same at every stage):
     out = A(A(u; c); c) in one launch == two launches == the oracle's chained applies, bit for bit; chunk seams, window
     seams along J and K in both element types; a step loop over the pair entry"""
-    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(tmp_path))
-    import test_multihalo_gpu as mh
+    monkeypatch.setenv("NEPTUNE_CACHE_DIR", str(wide_cache))
     from neptune_hip import lowering
     elem, shape, nin, rad = WIDE_CASES[name]
-    acc = [(0, (0, 0, 0))]
-    for d in range(3):
-        for sdist in range(1, rad[d] + 1):
-            for sign in (-1, 1):
-                o = [0, 0, 0]
-                o[d] = sign * sdist
-                acc.append((0, tuple(o)))
-    acc += [(k, (0, 0, 0)) for k in range(1, nin)]
-    lb, ub = list(rad), [n - r for n, r in zip(shape, rad)]
-    text = mh.module_text(shape, elem, nin, acc, lb, ub)
+    text, lb, ub = wide_case_text(name)
     mod = lowering.compile_module(text)
     entry = mod.geom_entry("resid")
     npdt = np.float32 if elem == "f32" else np.float64
@@ -266,14 +294,15 @@ def test_chains_beyond_the_7_point_family(nh, name, tmp_path, monkeypatch):
     import ctypes as C
     g = nh.apply.geom_for([fin] + fco, out, bounds)
     ins = nh.apply._in_array([fin] + fco)
-    wide = max(rad) > 1
-    for chunk in (0, 3):
+    wide = max(rad) > 1 and len(shape) == 3
+    for chunk in (0, 3 if len(shape) == 3 else 40):
         out.tensor.fill_(float("nan"))
         cfg = nh.apply.make_cfg(chunk=chunk)
         assert entry.fn2(C.byref(g), ins, out.ptr, None, C.byref(cfg)) == 0
         nh.torch.cuda.synchronize()
         assert helpers.bits_equal(out.numpy(), chain[2]), f"{name} chunk {chunk}\n" + helpers.mismatch_report(out.numpy(), chain[2])
-    # three applies per pass: the radius-1 footprints take it, radius 2 declines (three rings of five planes do not fit)
+    # three applies per pass: the radius-1 footprints and every rank-2 one take it, rank-3 radius 2 declines (three rings of
+    # five planes do not fit)
     rc3 = entry.fn3(C.byref(g), ins, out.ptr, None, None)
     if wide:
         assert rc3 == nh.capi.EUNSUPPORTED

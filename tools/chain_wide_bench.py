@@ -19,6 +19,8 @@ def main():
     from neptune_hip import _capi, apply, fields, lowering
     lib = _capi.load()
     lib.neptune_hip_init(0)
+    if "--2d" in sys.argv:
+        return main_2d(torch, mh, _capi, apply, fields, lowering)
     sizes = [int(x) for x in sys.argv[1:] if x.isdigit()] or [512]
     fix13 = (REPO / "tests/mlir_tests/conversion_tests/apply-3d-13pt.mlir").read_text()
     for n in sizes:
@@ -76,6 +78,45 @@ module {{
                 o.tensor.mul_(1e-3)
             steps = 60 if n >= 1024 else 204
             row = {"field": f"{n}^3 f64", "body": name, "steps": steps, "shape": os.environ.get("NEPTUNE_HIP_MARCH2", "0")}
+            for label, env in (("one", "NEPTUNE_HIP_NO_PAIRS"), ("two", "NEPTUNE_HIP_NO_TRIPLES"), ("three", "")):
+                os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
+                os.environ.pop("NEPTUNE_HIP_NO_TRIPLES", None)
+                if env:
+                    os.environ[env] = "1"
+                apply.step_loop(entry, a, b, bounds, 60, others=others)
+                a.fill_hash(5)
+                a.tensor.mul_(1e-3)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                apply.step_loop(entry, a, b, bounds, steps, others=others)
+                torch.cuda.synchronize()
+                row[label + "_ms_per_step"] = round((time.perf_counter() - t0) * 1e3 / steps, 4)
+            row["speedup2"] = round(row["one_ms_per_step"] / row["two_ms_per_step"], 3)
+            row["speedup3"] = round(row["one_ms_per_step"] / row["three_ms_per_step"], 3)
+            print(json.dumps(row), flush=True)
+            del a, b, others
+            torch.cuda.empty_cache()
+
+
+def main_2d(torch, mh, _capi, apply, fields, lowering):
+    """rank 2: generated weighted stars (5-point, 9-point radius 2) with and without a coefficient field"""
+    sizes = [int(x) for x in sys.argv[1:] if x.isdigit()] or [8192]
+    for n in sizes:
+        shape = (n, n)
+        for name, nin, r in (("5-tap weighted star + index term", 1, 1), ("9-tap radius-2 star + index term", 1, 2),
+                             ("5-tap star + coefficient field", 2, 1), ("9-tap radius-2 star + coefficient field", 2, 2)):
+            acc = [(0, o) for o in mh.star(2, r)] + [(k, (0, 0)) for k in range(1, nin)]
+            bounds = ([r] * 2, [n - r] * 2)
+            mod = lowering.compile_module(mh.module_text(shape, "f64", nin, acc, bounds[0], bounds[1]))
+            entry = mod.geom_entry("resid")
+            a = fields.DeviceField.hashed(shape, _capi.F64, seed=5)
+            a.tensor.mul_(1e-3)
+            b = fields.DeviceField.empty_like(a)
+            others = [fields.DeviceField.hashed(shape, _capi.F64, seed=7 + k) for k in range(1, nin)]
+            for o in others:
+                o.tensor.mul_(1e-3)
+            steps = 408
+            row = {"field": f"{n}^2 f64", "body": name, "steps": steps}
             for label, env in (("one", "NEPTUNE_HIP_NO_PAIRS"), ("two", "NEPTUNE_HIP_NO_TRIPLES"), ("three", "")):
                 os.environ.pop("NEPTUNE_HIP_NO_PAIRS", None)
                 os.environ.pop("NEPTUNE_HIP_NO_TRIPLES", None)
