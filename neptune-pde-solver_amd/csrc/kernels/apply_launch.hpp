@@ -446,15 +446,10 @@ inline int plan_apply(const neptune_hip_apply_geom_t* g, const void* const* in, 
       if (d > 0 || RANK == 1) kplane *= n;
     }
     ok = ok && kplane < 0x7fffffffLL && (k > 0 || same);
-    if (!same) {
-      // cells of this input to the right of the result's rows (a field on the K faces, ghost cells) may be read by the
-      // result's last cells.  At the end of a wave's span they arrive as halo cells (element loads, clamped per cell); in
-      // the middle of one they are the next lane's vector, which must then exist as a whole: the rows end on a span
-      // boundary, or the input has a whole lane vector of cells there -- or none at all.  (The LDS kernels fetch halo cells
-      // at the end of a WINDOW: launch_apply_impl keeps such inputs off windows wider than one span.)
-      const int64_t n2 = g->out_ub[RANK - 1] - g->out_lb[RANK - 1], extra = g->in_ub[k][RANK - 1] - g->out_ub[RANK - 1];
-      ok = ok && (extra == 0 || extra >= VK || n2 % ((int64_t)kWave * VK) == 0);
-    }
+    // (cells of such an input right of the result's rows -- a field on the K faces, ghost cells -- may be read by the
+    // result's last cells: at the end of a wave's span or an LDS window they arrive as halo cells, clamped per element; in
+    // the middle of one they are the next lane's vector, whose load is clamped to the row's last whole vector and rotated
+    // into place when it is consumed: InView::fix_k / fix_d)
     // rows of an input in the result's box start on 16-byte boundaries with it; a box of its own puts them anywhere (the
     // loads are then unaligned 16-byte accesses, like ragged rows)
     ok = ok && ((uintptr_t)in[k] % (same ? 16 : sizeof(T)) == 0);
@@ -633,16 +628,6 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     int variant = pick_march_variant<T, RANK, FP>(g, cfg);
     if (RANK == 3 && variant == 6 && !(cfg && cfg->variant == 6) && march3_variant_scratch<Body, T, RANK, NIN, FP>(6) > 0)
       variant = 4;  // automatic choice only: this body spills on the 8-rows-per-lane tile
-    if constexpr (NIN > 1) {
-      // an input with fewer than a lane vector of cells right of the result's rows relies on the halo cells at the end of a
-      // wave's span (plan_apply); the LDS kernels fetch theirs at the end of a window: keep it on one-span-wide windows
-      const MarchVariant* mv = march_variant(RANK, variant);
-      if (mv && mv->pln && mv->WK > 1)
-        for (int k = 1; k < NIN; ++k) {
-          const int64_t extra = g->in_ub[k][RANK - 1] - g->out_ub[RANK - 1];
-          if (extra > 0 && extra < (int64_t)(16 / sizeof(T))) variant = RANK == 3 ? 7 : 0;   // pln_rj4_wj8_wk1 / tile_rj4_wj8_wk1
-        }
-    }
     // rank-2 tile form: (d0,d1) -> (J,K), one plane (the LDS tile kernel is a tile form whatever the table row says)
     const bool jk = RANK == 2 && (march_variant(RANK, variant)->jk || tile2_only<T, FP, RANK>());
     auto axes = [&](const int64_t* src, int64_t dst[3], int64_t fill) {
@@ -685,6 +670,13 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
           vw.lo[a] = (int32_t)-s3[a];
           vw.hi[a] = (int32_t)(kn[a] - s3[a] - 1);
         }
+        // the first lane vector (starts are multiples of VK) that does not fit the input's row as a whole, if the row still
+        // holds cells of it
+        constexpr int VKc = 16 / (int)sizeof(T);
+        const int32_t kmax = vw.hi[2] - VKc + 1;
+        const int32_t kstar = kmax < 0 ? 0 : (kmax / VKc + 1) * VKc;     // smallest multiple of VK above kmax
+        vw.fix_k = kstar;
+        vw.fix_d = (kstar <= vw.hi[2] && kstar - kmax < VKc) ? kstar - kmax : 0;
       }
     }
     P.rJ0 = 0; P.rJ1 = P.N1;

@@ -50,6 +50,11 @@ struct InView {
   int32_t row_b;          // bytes from one row to the next
   int32_t sh[3];          // (out_lb - in_lb) per kernel axis: result-physical -> input-physical
   int32_t lo[3], hi[3];   // result-physical coordinates the input holds, inclusive: [-sh, extent - sh - 1]
+  // The lane right of the result's last vector may find fewer than a lane vector of cells in this input's row (a field
+  // on the K faces: ONE more cell).  Its load is clamped to the last whole vector of the row, so the cells it is asked for
+  // sit fix_d elements further up in what it loaded: the lane whose vector starts at fix_k rotates its vector down by
+  // fix_d elements when the vector is consumed (view_fix; fix_d == 0: nothing to do).
+  int32_t fix_k, fix_d;
 };
 
 template <class T, int NIN>
@@ -119,6 +124,24 @@ __device__ __forceinline__ const char* view_plane_base(const MarchParams<T, NIN>
 template <class T> struct Vec16;
 template <> struct Vec16<double> { typedef double type __attribute__((ext_vector_type(2))); };
 template <> struct Vec16<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// InView::fix_k / fix_d: `star` = this lane's vector starts at fix_k (per lane), d = fix_d (wave-uniform, 0 = no fix)
+template <class T>
+__device__ __forceinline__ typename Vec16<T>::type view_fix(typename Vec16<T>::type v, bool star, int32_t d) {
+  if (d != 0) {
+    if constexpr (sizeof(T) == 8) {
+      v[0] = star ? v[1] : v[0];                       // VK = 2: d can only be 1
+    } else {
+      if (d & 1) { const bool c = star; typename Vec16<T>::type w = v; v[0] = c ? w[1] : w[0]; v[1] = c ? w[2] : w[1]; v[2] = c ? w[3] : w[2]; }
+      if (d & 2) { const bool c = star; typename Vec16<T>::type w = v; v[0] = c ? w[2] : w[0]; v[1] = c ? w[3] : w[1]; }
+    }
+  }
+  return v;
+}
+template <class T, int NIN>
+__device__ __forceinline__ int32_t view_fix_d(const MarchParams<T, NIN>& P, int n) { return (NIN > 1 && n > 0) ? P.view[n].fix_d : 0; }
+template <class T, int NIN>
+__device__ __forceinline__ bool view_fix_star(const MarchParams<T, NIN>& P, int n, int32_t k) { return NIN > 1 && n > 0 && k == P.view[n].fix_k; }
 
 // ---- wave shifts ----------------------------------------------------------------------
 // from_prev: lane l receives x of lane l-1, lane 0 receives `edge`.
@@ -337,7 +360,14 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
   const int32_t kw_end = kw + kWave * VK;
   // ... per input when there are several: an input in a box of its own may hold whole vectors right of the result's rows
   uint32_t lane_bv[NIN > 1 ? NIN : 1];
-  static_for<(NIN > 1 ? NIN : 1)>([&](auto nc) { constexpr int n = nc; lane_bv[n] = view_lane_bytes(P, n, k0); });
+  int32_t fixd[NIN > 1 ? NIN : 1];     // InView::fix_d per input (wave-uniform) and whether this lane is the one to fix
+  bool fixs[NIN > 1 ? NIN : 1];
+  static_for<(NIN > 1 ? NIN : 1)>([&](auto nc) {
+    constexpr int n = nc;
+    lane_bv[n] = view_lane_bytes(P, n, k0);
+    fixd[n] = view_fix_d(P, n);
+    fixs[n] = view_fix_star(P, n, k0);
+  });
 
   const int32_t ib = P.rI0 + (int32_t)ct * P.chunk;
   const int32_t ie = (ib + P.chunk < P.rI1) ? ib + P.chunk : P.rI1;
@@ -518,6 +548,19 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
     });
   });
   load_point_inputs(ib, npt);
+  if constexpr (NIN > 1) {
+    // the prologue's planes went straight into the ring: the same fix, once
+    static_for<NH>([&](auto hc) {
+      constexpr int h = hc, hin = halo_input_of(HMASK, h);
+      if constexpr (hin > 0) {
+        if (fixd[hin] != 0)
+          static_for<NP - 1>([&](auto pc) {
+            constexpr int p = pc;
+            static_for<NR>([&](auto sc) { constexpr int s = sc; ring[h][p + 1][s] = view_fix<T>(ring[h][p + 1][s], fixs[hin], fixd[hin]); });
+          });
+      }
+    });
+  }
 
   // one plane step; `slot` (compile-time) names the in-flight buffer holding plane i+R0, so no
   // register that a load is still writing is ever moved
@@ -540,9 +583,13 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
           }
         });
       });
+      constexpr int hin = halo_input_of(HMASK, h);
       static_for<NR>([&](auto sc) {
         constexpr int s = sc;
-        if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) ring[h][NP - 1][s] = nxt[h][slot][s];
+        if constexpr (!JH_LATE || (s >= R1 && s < R1 + RJ)) {
+          if constexpr (NIN > 1 && hin > 0) ring[h][NP - 1][s] = view_fix<T>(nxt[h][slot][s], fixs[hin], fixd[hin]);
+          else ring[h][NP - 1][s] = nxt[h][slot][s];
+        }
         static_for<NS>([&](auto xc) {
           constexpr int x = xc;
           khl[h][NPH - 1][s][x] = nkhl[h][kslot][s][x];
@@ -554,7 +601,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_march(Mar
         // without the LDS exchange, by the workgroup's outermost waves with it)
         static_for<2 * R1>([&](auto xc) {
           constexpr int x = xc;
-          ring[h][PJ][x < R1 ? x : RJ + x] = njh[h][slot][x];
+          if constexpr (NIN > 1 && hin > 0) ring[h][PJ][x < R1 ? x : RJ + x] = view_fix<T>(njh[h][slot][x], fixs[hin], fixd[hin]);
+          else ring[h][PJ][x < R1 ? x : RJ + x] = njh[h][slot][x];
         });
       }
     });

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   uint32_t hsrc[NHWX];      // byte offset within a plane of my 16 bytes of the unit
   int32_t hdst[NHWX];       // LDS cell index (within one buffer) they go to; -1: no unit
   int hin[NHWX];            // the unit's input
+  bool hfix[NHWX];          // ... and whether my vector of it is the one InView::fix_k names
   static_for<NHW>([&](auto tc) {
     constexpr int tt = tc;
     const int uu = w + tt * NW;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
     static_for<NH>([&](auto hc) { constexpr int h = hc; if (hh == h) hin[tt] = halo_input_of(HMASK, h); });
     hsrc[tt] = view_row_bytes(P, hin[tt], x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1)) + view_lane_bytes(P, hin[tt], kc);
     hdst[tt] = uu < NUA ? hh * WIN + (x < R1 ? x : TJ + x) * LROW + HK + sp * SPAN + lane * VK : -1;
+    hfix[tt] = view_fix_star(P, hin[tt], kc);
   });
   // halo cells beside my own rows: lanes [0,HK) the cells left of the window (its leftmost waves), lanes [HK,2HK) the
   // cells right of it (its rightmost waves); clamped per cell
@@ -239,13 +241,18 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_plane(Mar
   auto lay_out = [&](int b, auto slot_c) {
     constexpr int sl = decltype(slot_c)::value;
     T* buf = &lds[b][0][0][0];
+    // (an input in a box of its own with fewer than a lane vector of cells right of the result's rows: the lane there lays
+    // its clamped vector out rotated into place, InView::fix_k / fix_d)
     static_for<NH>([&](auto hc) {
-      constexpr int h = hc;
-      static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) = ring[h][sl][r]; });
+      constexpr int h = hc, n = halo_input_of(HMASK, h);
+      static_for<RJ>([&](auto rc) {
+        constexpr int r = rc;
+        *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) = view_fix<T>(ring[h][sl][r], view_fix_star(P, n, k0), view_fix_d(P, n));
+      });
     });
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
-      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[tt];
+      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = view_fix<T>(jh[tt], hfix[tt], view_fix_d(P, hin[tt]));
     });
     if constexpr (R2 > 0) {
       if (kh_any) static_for<NH>([&](auto hc) {
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
   // halo-row units of this wave (row x of the 2*R1 halo rows, wave span s), each with the window's corner cells beside it
   uint32_t hsrc[NHWX], hcsrc[NHWX];
   int32_t hdst[NHWX], hcdst[NHWX];
-  bool hc_any[NHWX];
+  bool hc_any[NHWX], hfix[NHWX];
   static_for<NHW>([&](auto tc) {
     constexpr int tt = tc;
     const int u = w + tt * NW;
@@ -456,6 +463,7 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
     const uint32_t rb = row_bytes(x < R1 ? j0w - R1 + x : j0w + TJ + (x - R1));
     const int32_t lrow = (x < R1 ? x : TJ + x) * LROW;
     hsrc[tt] = rb + view_lane_bytes(P, HIN, kc);
+    hfix[tt] = view_fix_star(P, HIN, kc);
     hdst[tt] = u < NU ? lrow + HK + sp * SPAN + lane * VK : -1;
     hcsrc[tt] = rb + cell_b;
     hcdst[tt] = lrow + cell_col;
@@ -485,10 +493,13 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_planes(Ma
   auto lay_out = [&](int b, auto dc) {
     constexpr int d = decltype(dc)::value;
     T* buf = &lds[0][0][0] + b * PLANE;
-    static_for<RJ>([&](auto rc) { constexpr int r = rc; *reinterpret_cast<V*>(buf + own_cell + r * LROW) = nxt[d][r]; });
+    static_for<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      *reinterpret_cast<V*>(buf + own_cell + r * LROW) = view_fix<T>(nxt[d][r], view_fix_star(P, HIN, k0), view_fix_d(P, HIN));
+    });
     static_for<NHW>([&](auto tc) {
       constexpr int tt = tc;
-      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[d][tt];
+      if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = view_fix<T>(jh[d][tt], hfix[tt], view_fix_d(P, HIN));
       if (hc_any[tt]) buf[hcdst[tt]] = hc[d][tt];
     });
     if constexpr (R2 > 0) {
@@ -671,8 +682,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
   V jh[NHWX];
   T hc[NHWX];
   V pt[NIN][RJ];
-  int32_t hdst[NHWX], hcdst[NHWX];
-  bool hc_any[NHWX];
+  int32_t hdst[NHWX], hcdst[NHWX], jfixd[NHWX];
+  bool hc_any[NHWX], jfix[NHWX];
   static_for<NH>([&](auto hcn) {
     constexpr int h = hcn;
     constexpr int n = halo_input_of(HMASK, h);
@@ -701,6 +712,8 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
     const char* base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, 0)]);
     static_for<NH>([&](auto hcn) { constexpr int h = hcn; if (hh == h) base = reinterpret_cast<const char*>(P.in[halo_input_of(HMASK, h)]); });
     if (hdst[tt] >= 0) jh[tt] = *reinterpret_cast<const V*>(base + (rb + view_lane_bytes(P, n, kc)));
+    jfix[tt] = view_fix_star(P, n, kc);
+    jfixd[tt] = view_fix_d(P, n);
     if (hc_any[tt]) hc[tt] = *reinterpret_cast<const T*>(base + (rb + view_cell_bytes(P, n, cell_k)));
   });
   static_for<NIN>([&](auto nc) {
@@ -716,13 +729,14 @@ __global__ __launch_bounds__(kWave* TL::WJ* TL::WK) void neptune_apply_tile2(Mar
     constexpr int h = hcn;
     static_for<RJ>([&](auto rc) {
       constexpr int r = rc;
-      *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) = own[h][r];
+      *reinterpret_cast<V*>(buf + h * WIN + own_cell + r * LROW) =
+          view_fix<T>(own[h][r], view_fix_star(P, halo_input_of(HMASK, h), k0), view_fix_d(P, halo_input_of(HMASK, h)));
       if constexpr (R2 > 0) { if (kh_any) buf[h * WIN + (R1 + wj * RJ + r) * LROW + cell_col] = kh[h][r]; }
     });
   });
   static_for<NHW>([&](auto tc) {
     constexpr int tt = tc;
-    if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = jh[tt];
+    if (hdst[tt] >= 0) *reinterpret_cast<V*>(buf + hdst[tt]) = view_fix<T>(jh[tt], jfix[tt], jfixd[tt]);
     if (hc_any[tt]) buf[hcdst[tt]] = hc[tt];
   });
   __syncthreads();

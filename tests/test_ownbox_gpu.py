@@ -1,7 +1,7 @@
 """Inputs that live in boxes of their own on the fast kernels.  The reference's apply only asks that input 0 has the
 result's shape (DataflowLowering.cpp:283-287); inputs 1.. index through their OWN lower bounds (:382-410) -- a
 face-located field of extent N+1 beside a cell-located result (staggered grids), a field that carries its ghost layers.
-Such an input used to send the whole apply to the direct kernel; now the march / plane-in-LDS / rank-2 tile kernels read
+Such an input used to send the whole apply to the direct kernel; the march / plane-in-LDS / rank-2 tile kernels read
 it through a per-input view (MarchParams::view: own pitch, shift, clamp range) whenever its box contains the result's.
 Every case: lowered from NeptuneIR text, bit for bit against the oracle on the automatic tile, on every default tile with
 chunk seams inside the field and on the direct kernel; and the launch really is the march kernel."""
@@ -111,10 +111,32 @@ def _cases():
     c["staggered_2d"] = ("f64", o2, o2, [o2, grow(o2, (0, 0), (1, 0)), grow(o2, (1, 1), (1, 1))],
                          [(0, (0, 0)), (1, (0, 0)), (1, (1, 0)), (2, (0, 0))] + [(2, o) for o in star(2, 1)])
     c["ghosted_radius5_2d"] = ("f64", o2, o2, [o2, grow(o2, (5, 5), (5, 5))], [(0, (0, 0)), (1, (0, 0))] + [(1, o) for o in star(2, 5)])
+    # fewer than a lane vector of cells right of rows that end INSIDE a wave's span: the lane past the result's last vector
+    # loads the row's last whole vector and rotates it into place (InView::fix_k / fix_d) -- f64 by one element, f32 by
+    # three, two and one; on the march tiles, the plane-in-LDS kernels and the rank-2 tile kernels
+    obm = box((0, 0, 0), (6, 8, 130))
+    c["kfaces_mid_span_f64"] = ("f64", obm, obm, [obm, grow(obm, (0, 0, 0), (0, 0, 1))], [(0, (0, 0, 0)), (1, (0, 0, 0)), (1, (0, 0, 1))])
+    obn = box((0, 0, 0), (6, 9, 520))
+    for extra in (1, 2, 3):
+        c[f"kfaces_mid_span_f32_plus{extra}"] = ("f32", obn, obn, [obn, grow(obn, (0, 0, 0), (0, 0, extra))],
+                                                 [(0, (0, 0, 0))] + [(1, (0, 0, e)) for e in range(extra + 1)])
+    c["ghosted_7pt_mid_span_f64"] = ("f64", obm, obm, [obm, grow(obm, (1, 1, 1), (1, 1, 1))], [(0, (0, 0, 0)), (1, (0, 0, 0))] + [(1, o) for o in star(3, 1)])
+    c["ghosted_27pt_mid_span_f32"] = ("f32", obn, obn, [obn, grow(obn, (1, 1, 1), (1, 1, 1))],
+                                      [(0, (0, 0, 0))] + [(1, (a, b, cc)) for a in (-1, 0, 1) for b in (-1, 0, 1) for cc in (-1, 0, 1)])
+    c["ghosted_radius3_star_mid_span_f32"] = ("f32", obn, obn, [obn, grow(obn, (3, 3, 3), (3, 3, 3))], [(0, (0, 0, 0)), (1, (0, 0, 0))] + [(1, o) for o in star(3, 3)])
+    c["ghosted_radius5_star_mid_span_f64"] = ("f64", obm, obm, [obm, grow(obm, (5, 5, 5), (5, 5, 5))], [(0, (0, 0, 0)), (1, (0, 0, 0))] + [(1, o) for o in star(3, 5)])
+    o2m = box((0, 0), (40, 130))
+    c["staggered_2d_mid_span"] = ("f64", o2m, o2m, [o2m, grow(o2m, (0, 0), (0, 1)), grow(o2m, (1, 1), (1, 1))],
+                                  [(0, (0, 0)), (1, (0, 0)), (1, (0, 1)), (2, (0, 0))] + [(2, o) for o in star(2, 1)])
+    o2n = box((0, 0), (40, 520))
+    c["ghosted_radius5_2d_mid_span_f32"] = ("f32", o2n, o2n, [o2n, grow(o2n, (5, 5), (5, 5))], [(0, (0, 0)), (1, (0, 0))] + [(1, o) for o in star(2, 5)])
     # rank 1
     o1 = box((0,), (4096,))
     c["staggered_1d"] = ("f64", o1, o1, [o1, grow(o1, (0,), (1,)), grow(o1, (2,), (2,))],
                          [(0, (0,)), (1, (0,)), (1, (1,)), (2, (-2,)), (2, (2,)), (2, (0,))])
+    o1m = box((0,), (1000,))
+    c["staggered_1d_mid_span_f32"] = ("f32", o1m, o1m, [o1m, grow(o1m, (0,), (1,)), grow(o1m, (2,), (2,))],
+                                      [(0, (0,)), (1, (0,)), (1, (1,)), (2, (-2,)), (2, (2,)), (2, (0,))])
     return c
 
 
@@ -179,20 +201,3 @@ def test_inputs_in_their_own_boxes_run_the_fast_kernels(env, name):
     if bounds != ob:
         lo = [b - o for b, o in zip(bounds[0], ob[0])]
         assert bits_equal(want[tuple(slice(0, max(l, 1)) for l in lo)], ins[0][tuple(slice(0, max(l, 1)) for l in lo)]) or any(l == 0 for l in lo)
-
-
-def test_a_face_field_on_rows_that_end_inside_a_wave_span_stays_on_the_direct_kernel(env):
-    """the one shape the fast kernels leave to the direct kernel: ONE extra cell to the right of rows that do not end on a
-    span boundary (the next lane's 16-byte vector would not exist as a whole); still bit-exact"""
-    lowering, torch, capi = env
-    ob = box((0, 0, 0), (6, 8, 130))
-    text = module_text("f64", ob, ob, [ob, grow(ob, (0, 0, 0), (0, 0, 1))], [(0, (0, 0, 0)), (1, (0, 0, 0)), (1, (0, 0, 1))])
-    ins = [helpers.hash_field((6, 8, 130), np.float64, seed=5), helpers.hash_field((6, 8, 131), np.float64, seed=6)]
-    want = np.zeros((6, 8, 130))
-    oracle.Module.parse(text).call("entry", want, *ins)
-    mod = lowering.compile_module(text)
-    d_out = torch.zeros((6, 8, 130), dtype=torch.float64, device="cuda")
-    mod.call("entry", d_out, *[torch.from_numpy(a).cuda() for a in ins])
-    assert bits_equal(d_out.cpu().numpy(), want)
-    last = capi.LaunchCfg()
-    assert capi.load().neptune_hip_last_launch(C.byref(last)) == 1 and last.kernel == capi.KERNEL_DIRECT
