@@ -321,6 +321,15 @@ inline void launch_march_variant(MarchParams<T, NIN>& P, const Body& body, int64
   // a K radius beyond one vector reads two lanes to the right: leave one more vector of ragged rows to the tail
   P.Ks = (P.N2 % VK == 0) ? P.N2 : P.Kl - ragged_extra_vectors<FP, VK>() * VK;
   P.nK = (uint32_t)((P.Ks + tileK - 1) / tileK);
+  if constexpr (RANK == 3) {
+    // A last row tile that would hold only a few rows costs a whole column of workgroups (2^k+1 grids: ONE row in the 33rd
+    // tile of 32, and 33 x 8 x 2 workgroups no longer fit the 512 slots that 32 x 8 x 2 fill exactly): those rows are left
+    // to the caller's direct launch, next to the ragged row ends (MarchParams::rJ1 tells it which).  NEPTUNE_HIP_ROW_TAIL=0
+    // keeps them here (measurements).
+    static const bool row_tail = [] { const char* e = getenv("NEPTUNE_HIP_ROW_TAIL"); return !(e && e[0] == '0'); }();
+    const int64_t rowsJ = P.rJ1 - P.rJ0, rem = rowsJ % tileJ;
+    if (row_tail && rowsJ > tileJ && rem > 0 && rem * 8 <= tileJ) P.rJ1 -= (int32_t)rem;
+  }
   P.nJ = (uint32_t)((P.rJ1 - P.rJ0 + tileJ - 1) / tileJ);
   const int64_t tilesJK = (int64_t)P.nJ * P.nK;
   int64_t chunk = chunk_req;
@@ -690,14 +699,22 @@ inline int launch_apply_impl(const Body& body, const neptune_hip_apply_geom_t* g
     }
     launch_march<Body, T, RANK, NIN, FP>(variant, P, body, P.rI1 - P.rI0, cfg ? cfg->chunk : 0, stream);
     neptune_hip_note_launch(NEPTUNE_HIP_KERNEL_MARCH, variant, P.chunk);
+    int rc = NEPTUNE_HIP_OK;
     if (P.N2 % (16 / (int)sizeof(T)) != 0) {
-      // ragged rows: cells [Ks, N2) of every row of the region -- fewer than 3*VK per row -- through the
+      // ragged rows: cells [Ks, N2) of every row the march launch stored -- fewer than 3*VK per row -- through the
       // flat direct kernel (lanes run down the rows: strided, but a fraction of a percent of the field)
       neptune_hip_apply_geom_t tail = *g;
       tail.region_lb[RANK - 1] = P.Ks;
-      return launch_direct<Body, T, RANK, NIN>(body, &tail, in, out, stream, true);
+      if (RANK == 3 && !jk) tail.region_ub[1] = P.rJ1;
+      rc = launch_direct<Body, T, RANK, NIN>(body, &tail, in, out, stream, true);
     }
-    return NEPTUNE_HIP_OK;
+    if (RANK == 3 && !jk && P.rJ1 < P.N1 && rc == NEPTUNE_HIP_OK) {
+      // the few rows past the last whole row tile (launch_march_variant): whole rows, lanes along them
+      neptune_hip_apply_geom_t rows = *g;
+      rows.region_lb[1] = P.rJ1;
+      rc = launch_direct<Body, T, RANK, NIN>(body, &rows, in, out, stream, false);
+    }
+    return rc;
   }
 
   neptune_hip_note_launch(NEPTUNE_HIP_KERNEL_DIRECT, -1, 0);

@@ -57,9 +57,11 @@ SHAPES = {
     # incl. ragged rows (last extent not a multiple of the 16-byte lane vector: 2^k+1 node-centred grids)
     "2d5": [(3, 3), (5, 8), (17, 130), (40, 256), (33, 1024), (64, 1280), (9, 37), (33, 1025), (19, 131), (7, 5)],
     "3d7": [(3, 3, 4), (8, 8, 8), (6, 7, 130), (20, 18, 128), (33, 17, 256), (12, 70, 384), (5, 9, 11), (9, 10, 257),
-            (6, 7, 131), (17, 9, 129)],
+            (6, 7, 131), (17, 9, 129),
+            # a row or two past the last whole row tile (2^k+1 rows): those rows leave the march launch for a direct one
+            (6, 33, 130), (5, 66, 131), (4, 129, 128)],
     "3d27": [(3, 3, 4), (8, 8, 8), (6, 7, 132), (20, 18, 256), (9, 33, 512), (5, 9, 11), (6, 7, 133), (5, 9, 259),
-             (7, 6, 130), (4, 5, 9)],
+             (7, 6, 130), (4, 5, 9), (5, 65, 260), (5, 34, 133)],
 }
 
 
