@@ -31,6 +31,8 @@ def main():
         body = apply.BODY_BY_NAME[body_name]
         vk = 16 // np.dtype(dt).itemsize
         shape = [int(rng.integers(3, 40)) for _ in range(rank - 1)]
+        if rank == 3 and rng.random() < 0.3:     # a row or two past the last whole row tile (2^k+1 rows): the row-tail launch
+            shape[1] = int(rng.choice([33, 34, 65, 66, 68, 129, 130]))
         last = int(rng.choice([vk * 3, 30, 64, 126, 128, 129, 130, 131, 200, 255, 256, 257, 300, 384, 385, 513, 640]))
         shape.append(max(last, vk * 3))
         origin = [int(rng.integers(-9, 10)) for _ in range(rank)]
