@@ -92,6 +92,11 @@ struct Footprint {
   int R[3] = {0, 0, 0};  // shared radii on the kernel's (I,J,K) axes
   bool march_ok = true;
   int lead = 0;          // leading (batch / component) dimensions of an apply of rank 4..6: peeled off on the host
+  // rank 4..6 with offsets along a leading dimension: a stencil in more than three dimensions, run by the rank-generic
+  // kernel (kernels/apply_nd.hpp) -- what its unconditional accesses reach per input and dimension, its reach along dim 0
+  bool nd = false;
+  int nd_lo[4][6], nd_hi[4][6];
+  int nd_halo0 = 0;
   bool exact = true;     // no elementary functions in the body
 };
 
@@ -101,6 +106,7 @@ struct Emitter {
   LowerInfo& info;
   std::ostringstream bodies, funcs, geom_entries;
   bool saw_elementary = false;  // set by emit_op when it emits exp/log/sin/cos/tanh/powf
+  bool nd_body = false;         // emitting the body of a Footprint::nd apply: accesses carry one offset per dimension
   int box_counter = 0;
   std::ostringstream consts;
   Emitter(const Module& mm, Diag& d, LowerInfo& i) : m(mm), diag(d), info(i) {}
@@ -157,7 +163,7 @@ struct Emitter {
       auto res = [&]() { return cname(op.results.at(0)); };
       if (n == "neptune_ir.access") {
         o << ind << "const " << ctype(op.types[1].elem) << " " << res() << " = a.template get<" << temp_index.at(op.operands[0]);
-        for (size_t d = op.offsets.size() > 3 ? op.offsets.size() - 3 : 0; d < op.offsets.size(); ++d) o << ", " << op.offsets[d];
+        for (size_t d = (op.offsets.size() > 3 && !nd_body) ? op.offsets.size() - 3 : 0; d < op.offsets.size(); ++d) o << ", " << op.offsets[d];
         o << ">();\n";
       } else if (n == "arith.constant") {
         const Type& t = op.types[0];
@@ -282,21 +288,29 @@ struct Emitter {
     for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d < lead ? -(d + 1) : d - lead;
     for (int k = 0; k < nin; ++k) temp_index[blk.args[rank + k].name] = k;
     if (lead > 0) {
-      std::function<bool(const Block&)> no_lead_offsets = [&](const Block& b) -> bool {
+      // an offset along a leading dimension makes it a stencil in more than three dimensions: the rank-generic kernel
+      for (int k = 0; k < 4; ++k)
+        for (int d = 0; d < 6; ++d) { fp.nd_lo[k][d] = 1; fp.nd_hi[k][d] = -1; }
+      std::function<void(const Block&, bool)> scan_nd = [&](const Block& b, bool top) {
         for (auto& op : b.ops) {
-          if (op->name == "neptune_ir.access")
-            for (int d = 0; d < lead; ++d)
-              if (op->offsets[d] != 0) {
-                diag.fail(op->line, "access with an offset along a leading dimension of a rank-" + std::to_string(rank) +
-                                        " apply (only the last three dimensions may carry offsets)");
-                return false;
+          if (op->name == "neptune_ir.access") {
+            const int k = temp_index.at(op->operands[0]);
+            for (int d = 0; d < rank; ++d) {
+              const int off = (int)op->offsets[d];
+              if (d < lead && off != 0) fp.nd = true;
+              if (d == 0) fp.nd_halo0 = std::max(fp.nd_halo0, std::abs(off));
+              if (top) {
+                if (fp.nd_hi[k][d] < fp.nd_lo[k][d]) fp.nd_lo[k][d] = fp.nd_hi[k][d] = off;
+                else { fp.nd_lo[k][d] = std::min(fp.nd_lo[k][d], off); fp.nd_hi[k][d] = std::max(fp.nd_hi[k][d], off); }
               }
-          for (auto& r : op->regions)
-            if (!no_lead_offsets(*r)) return false;
+            }
+          }
+          for (auto& r : op->regions) scan_nd(*r, false);
         }
-        return true;
       };
-      if (!no_lead_offsets(blk)) return false;
+      scan_nd(blk, true);
+      if (fp.nd)
+        for (int d = 0; d < rank; ++d) index_arg[blk.args[d].name] = d;   // every index argument through the accessor
     }
     // inputs never read unconditionally keep top_radius -1 ("not accessed": nothing to check)
     scan_accesses(blk, temp_index, fp, true);
@@ -394,10 +408,13 @@ struct Emitter {
     std::ostringstream& o = bodies;
     o << "// " << tag << ": region of the neptune_ir.apply at line " << apply.line << "\n";
     o << "struct Body_" << tag << " {\n";
-    if (rank > 3) o << "  int64_t lead[3] = {0, 0, 0};   // indices along the leading (batch) dimensions, set per launch\n";
+    if (rank > 3 && !fp.nd) o << "  int64_t lead[3] = {0, 0, 0};   // indices along the leading (batch) dimensions, set per launch\n";
     o << "  template <class A>\n  __device__ __forceinline__ " << ctype(res.elem) << " operator()(const A& a) const {\n";
     saw_elementary = false;
-    if (!emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr)) return false;
+    nd_body = fp.nd;
+    const bool body_ok = emit_region_ops(blk, o, "    ", temp_index, index_arg, nullptr);
+    nd_body = false;
+    if (!body_ok) return false;
     fp.exact = !saw_elementary;
     o << "  }\n};\n";
     o << "using FP_" << tag << " = neptune_hip::Footprint<" << fp.halo_input << ", " << R[0] << ", " << R[1] << ", " << R[2] << ", "
@@ -416,7 +433,22 @@ struct Emitter {
       }
       o << "}";
     }
-    o << "};\n\n";
+    o << "};\n";
+    if (fp.nd) {
+      o << "static const neptune_hip::ReachN kNdReach_" << tag << " = {";
+      for (int side = 0; side < 2; ++side) {
+        o << (side ? ", {" : "{");
+        for (int k = 0; k < 4; ++k) {
+          o << (k ? ", {" : "{");
+          for (int d = 0; d < 6; ++d)
+            o << (d ? ", " : "") << (k < nin && d < rank ? (side ? fp.nd_hi[k][d] : fp.nd_lo[k][d]) : (side ? -1 : 1));
+          o << "}";
+        }
+        o << "}";
+      }
+      o << "};\n";
+    }
+    o << "\n";
     return true;
   }
 
@@ -613,6 +645,26 @@ struct Emitter {
         o << "  const nl::Val* in_" << tag << "[] = {";
         for (int k = 0; k < nin; ++k) o << (k ? ", " : "") << "&" << cname(op.operands[k]);
         o << "};\n";
+        if (fp.nd) {
+          // rank 4..6 with offsets along a leading dimension: the rank-generic kernel (lowered_runtime.hpp run_apply_nd)
+          o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply_nd<Body_" << tag << ", " << ctype(res.elem) << ", "
+            << res.bounds.rank() << ", " << nin << ">(sc, Body_" << tag << "{}, " << new_box(res.bounds) << ", "
+            << new_box(op.attrs.at("bounds").bounds) << ", in_" << tag << ", kNdReach_" << tag << ", " << dest << ", " << fp.nd_halo0 << ");\n";
+          ApplyInfo ai;
+          ai.function = f.name;
+          ai.tag = tag;
+          ai.rank = res.bounds.rank();
+          ai.num_inputs = fp.nin;
+          ai.march = false;
+          ai.box = true;
+          ai.halo_input = 0;
+          ai.elem = res.elem;
+          ai.halo0 = fp.nd_halo0;
+          ai.geom_symbol = "";     // no geometry-level entry: neptune_hip_apply_geom_t is rank 1..3
+          ai.exact = fp.exact;
+          info.applies.push_back(ai);
+          continue;
+        }
         if (fp.lead > 0) {
           // rank 4..6: one rank-3 apply per index of the leading dimensions (lowered_runtime.hpp run_apply_batched)
           o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply_batched<Body_" << tag << ", " << ctype(res.elem) << ", "
@@ -686,7 +738,6 @@ struct Emitter {
         // reference's own explicit lowering (HighLevelConvertion.cpp:77-120) builds exactly this
         // apply_{linear,nonlinear} + axpy apply pair (its version is 1-D-only and ill-formed).
         const Type& st = op.types[0];
-        if (st.rank() > 3) { diag.fail(op.line, "neptune_ir.time_advance on a field of rank " + std::to_string(st.rank()) + " (rank 1..3 is lowered)"); return false; }
         ValueInfo vi;
         vi.type = st;
         vi.uses = vals[op.results[0]].uses;
@@ -702,7 +753,7 @@ struct Emitter {
         // two-kernel form below.  Both produce the same bits.
         const Function* c = m.find(op.callee);
         const Op* rhs_apply = nullptr;
-        if (c && c->arg_types.size() == 1 && c->body.ops.size() == 2 && c->body.ops[0]->name == "neptune_ir.apply" &&
+        if (st.rank() <= 3 && c && c->arg_types.size() == 1 && c->body.ops.size() == 2 && c->body.ops[0]->name == "neptune_ir.apply" &&
             c->body.ops[1]->name == "neptune_ir.return" && c->body.ops[1]->operands.size() == 1 &&
             c->body.ops[1]->operands[0] == c->body.ops[0]->results.at(0) && c->body.ops[0]->operands.size() == 1 &&
             c->body.ops[0]->operands[0] == c->body.args[0].name) {
@@ -770,6 +821,21 @@ struct Emitter {
         } else {
           o << "  // neptune_ir.time_advance {method = 0 (explicit), rhs = @" << op.callee << "}: state + dt * rhs(state)\n";
           o << "  const nl::Val k_" << tag << " = " << op.callee << "__impl(sc, " << cname(op.operands[0]) << ", nullptr, nullptr, nullptr);\n";
+          if (st.rank() > 3) {
+            // rank 4..6: the rhs through its own lowering (leading dimensions peeled off, or the rank-generic kernel), the
+            // axpy as one flat pointwise pass
+            o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_euler_axpy_flat<" << T << ">(sc, (" << T << ")" << cname(op.operands[1])
+              << ", " << cname(op.operands[0]) << ", k_" << tag << ", " << dest << ");\n";
+            ApplyInfo ai;
+            ai.function = f.name;
+            ai.tag = tag;
+            ai.rank = st.rank();
+            ai.num_inputs = 2;
+            ai.march = true;
+            ai.halo_input = -1;
+            info.applies.push_back(ai);
+            continue;
+          }
           o << "  const nl::Val* in_" << tag << "[] = {&" << cname(op.operands[0]) << ", &k_" << tag << "};\n";
           o << "  const nl::Val " << cname(op.results[0]) << " = nl::run_apply<neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank()
             << ">, " << T << ", " << st.rank() << ", 2, nl::PointwiseFP>(sc, neptune_hip::ops::EulerAxpy<" << T << ", " << st.rank() << ">{(" << T << ")"

@@ -33,6 +33,8 @@
 #include "../../../include/neptune_hip.h"
 #include "../kernels/apply_launch.hpp"
 #include "../kernels/apply_march2.hpp"
+#include "../kernels/apply_nd.hpp"
+#include "../kernels/body_ops.hpp"
 #include "../kernels/reduce_apply.hpp"
 
 namespace neptune_hip {
@@ -405,14 +407,19 @@ inline Val run_apply(Scope& sc, const Body& body, const Box& result_decl, const 
 // dimensions; the reference's lowering is rank-generic, DataflowLowering.cpp:268-270, 301-308): for every leading index one
 // rank-3 apply on the contiguous sub-field -- inside the leading bounds the body (which sees the leading indices as members
 // `lead[]`), outside them the copy-through of input 0 (DataflowLowering.cpp:283-287).  Every input must cover the result's
-// leading extent.  No slab mode (the slab axis would be a leading dimension).
+// leading extent.  Slab mode: dim 0, the slab axis, is a leading dimension here, so the apply never reaches into a
+// neighbouring plane: every rank runs its own leading indices (and the ghost planes too when its inputs' ghosts are good,
+// like run_apply with halo0 == 0).
 template <class Body, class T, int R, int NIN, class FP>
-inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
+inline Val run_apply_batched(Scope& sc, Body body, const Box& result_global, const Box& bounds_decl, const Val* const* in,
                              const neptune_hip::Reach& top_radius, const Val* dest) {
   static_assert(R > 3 && R <= kMaxBoxRank, "run_apply_batched: rank 4..6");
   constexpr int L = R - 3;
-  if (sc.slab()) die(sc.name(), "neptune_ir.apply of rank > 3 is not lowered in slab mode");
-  const Box bounds = Scope::zero_trip(bounds_decl);
+  bool inputs_fresh = true;
+  for (int k = 0; k < NIN; ++k) inputs_fresh = inputs_fresh && !in[k]->stale_ghosts;
+  const bool whole_local = sc.slab() && inputs_fresh;
+  const Box result_decl = sc.local_box(result_global);
+  const Box bounds = sc.owned_bounds(bounds_decl, whole_local);
   auto sub_box = [](const Box& b) {
     Box r;
     r.rank = 3;
@@ -435,6 +442,7 @@ inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const
   } else {
     out = sc.alloc(result_decl, (int)sizeof(T));
   }
+  out.stale_ghosts = sc.has_ghosts() && !whole_local;
   sc.wait_pending();
   const int64_t out_slab = out3.count();
   int64_t lead_n = 1;
@@ -476,6 +484,87 @@ inline Val run_apply_batched(Scope& sc, Body body, const Box& result_decl, const
     for (int d = 0; d < L; ++d) body.lead[d] = idx[d];
     rc = launch_apply<Body, T, 3, NIN, FP>(body, &g, ptrs, outp, sc.stream(), launch_override());
     if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.apply launch rejected");
+  }
+  if (direct) sc.mark_dirty(*dest);
+  return out;
+}
+
+// One neptune_ir.apply of rank R = 4..6 with offsets along its leading dimensions: a stencil in more than three dimensions
+// (kernels/apply_nd.hpp).  Same contract as run_apply, slab mode included (dim 0 is the slab axis whatever the rank); the
+// launch is not split around a pending halo exchange, it waits for it.
+template <class Body, class T, int R, int NIN>
+inline Val run_apply_nd(Scope& sc, const Body& body, const Box& result_decl, const Box& bounds_decl, const Val* const* in,
+                        const neptune_hip::ReachN& top_reach, const Val* dest, int halo0 = 0) {
+  static_assert(R > 3 && R <= kMaxBoxRank && R <= neptune_hip::kNdMaxRank, "run_apply_nd: rank 4..6");
+  bool inputs_fresh = true;
+  for (int k = 0; k < NIN; ++k) inputs_fresh = inputs_fresh && !in[k]->stale_ghosts;
+  if (sc.has_ghosts() && halo0 > 0 && !inputs_fresh)
+    die(sc.name(), "slab mode: neptune_ir.apply reads neighbouring planes of a value computed inside this call; "
+                   "its ghost planes would need a halo exchange in the middle of the function (split the function "
+                   "or run it on one GPU)");
+  const bool whole_local = sc.slab() && halo0 == 0 && inputs_fresh;
+  const Box result_box = sc.local_box(result_decl);
+  const Box bounds = sc.owned_bounds(bounds_decl, whole_local);
+  if (result_box.rank != R || bounds.rank != R) die(sc.name(), "malformed neptune_ir.apply geometry");
+  for (int k = 0; k < NIN; ++k)
+    if (in[k]->box.rank != R) die(sc.name(), "neptune_ir.apply: input rank differs from the result's");
+  if (!in[0]->box.same_shape(result_box))
+    die(sc.name(), "neptune_ir.apply: input 0 does not have the result's shape (DataflowLowering.cpp:283-287 copies it whole)");
+  // every unconditional access of every cell inside apply.bounds (and the result) must stay inside its input's box
+  for (int k = 0; k < NIN; ++k)
+    for (int d = 0; d < R; ++d) {
+      if (top_reach.hi[k][d] < top_reach.lo[k][d]) continue;
+      const int64_t p0 = bounds.lb[d] > result_box.lb[d] ? bounds.lb[d] : result_box.lb[d];
+      const int64_t p1 = bounds.ub[d] < result_box.ub[d] ? bounds.ub[d] : result_box.ub[d];
+      bool empty = false;
+      for (int e = 0; e < R; ++e) {
+        const int64_t a = bounds.lb[e] > result_box.lb[e] ? bounds.lb[e] : result_box.lb[e];
+        const int64_t b = bounds.ub[e] < result_box.ub[e] ? bounds.ub[e] : result_box.ub[e];
+        empty = empty || b <= a;
+      }
+      if (empty) continue;
+      if (p0 + top_reach.lo[k][d] < in[k]->box.lb[d] || p1 - 1 + top_reach.hi[k][d] >= in[k]->box.ub[d])
+        die(sc.name(), "neptune_ir.apply reads outside an input's bounds (undefined behaviour in the reference lowering, "
+                       "DataflowLowering.cpp:380-410); refusing to run it");
+    }
+  bool direct = dest != nullptr && dest->count == result_box.count();
+  for (int k = 0; direct && k < NIN; ++k) direct = !overlaps(*dest, *in[k]);
+  Val out;
+  if (direct) {
+    out = *dest;
+    out.box = result_box;
+  } else {
+    out = sc.alloc(result_box, (int)sizeof(T));
+  }
+  out.stale_ghosts = sc.has_ghosts() && !whole_local;
+  sc.wait_pending();
+  neptune_hip::NdParams<T, NIN> P{};
+  P.out = static_cast<T*>(out.dev);
+  P.inner = 1;
+  for (int d = 0; d < R; ++d) {
+    P.n[d] = result_box.ub[d] - result_box.lb[d];
+    P.olb[d] = result_box.lb[d];
+    P.lb[d] = bounds.lb[d];
+    P.ub[d] = bounds.ub[d];
+    if (d > 0) P.inner *= P.n[d];
+  }
+  for (int k = 0; k < NIN; ++k) {
+    P.in[k] = static_cast<const T*>(in[k]->dev);
+    for (int d = 0; d < R; ++d) {
+      P.m[k][d] = in[k]->box.ub[d] - in[k]->box.lb[d];
+      P.sh[k][d] = result_box.lb[d] - in[k]->box.lb[d];
+    }
+  }
+  P.r0 = 0;
+  P.r1 = P.n[0];
+  const int64_t total = (P.r1 - P.r0) * P.inner;
+  if (total > 0) {
+    const int64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) die(sc.name(), "neptune_ir.apply of rank > 3: the grid is not launchable");
+    hipLaunchKernelGGL((neptune_hip::neptune_apply_nd<Body, T, R, NIN>), neptune_hip::grid_for_blocks(blocks), dim3(256), 0, sc.stream(), P,
+                       body);
+    NEPTUNE_HIP_CHECK(hipGetLastError());
+    neptune_hip_note_launch(NEPTUNE_HIP_KERNEL_DIRECT, -1, 0);
   }
   if (direct) sc.mark_dirty(*dest);
   return out;
@@ -561,6 +650,40 @@ using PointwiseFP = Footprint<-1, 0, 0, 0, false, true>;
 static const neptune_hip::Reach kPointwiseRadius2 = {{{0, 0, 0}, {0, 0, 0}, {1, 1, 1}, {1, 1, 1}},        // two inputs read at the centre,
                                                     {{0, 0, 0}, {0, 0, 0}, {-1, -1, -1}, {-1, -1, -1}}};  // the others not at all (hi < lo)
 
+// The axpy step of an explicit time_advance on a field of rank 4..6: state + dt * k is pointwise over two dense buffers of
+// one shape, so it runs as ONE rank-1 apply over the flat buffers (the rank-1 march kernel: the copy kernel's access
+// pattern), whatever the rank -- and over everything this rank holds in slab mode, ghost planes included (they stay stale
+// if either operand's are).
+template <class T>
+inline Val run_euler_axpy_flat(Scope& sc, T dt, const Val& state, const Val& k, const Val* dest) {
+  if (!state.box.same_shape(k.box) || state.count != k.count)
+    die(sc.name(), "neptune_ir.time_advance: rhs(state) does not have the state's shape");
+  bool direct = dest != nullptr && dest->count == state.count && !overlaps(*dest, state) && !overlaps(*dest, k);
+  Val out;
+  if (direct) {
+    out = *dest;
+    out.box = state.box;
+  } else {
+    out = sc.alloc(state.box, (int)sizeof(T));
+  }
+  out.stale_ghosts = state.stale_ghosts || k.stale_ghosts;
+  sc.wait_pending();
+  if (state.count > 0) {
+    neptune_hip_apply_geom_t g;
+    memset(&g, 0, sizeof(g));
+    g.rank = 1;
+    g.num_inputs = 2;
+    g.out_ub[0] = g.ub[0] = g.region_ub[0] = state.count;
+    g.in_ub[0][0] = g.in_ub[1][0] = state.count;
+    const void* ptrs[2] = {state.dev, k.dev};
+    const int rc = launch_apply<neptune_hip::ops::EulerAxpy<T, 1>, T, 1, 2, PointwiseFP>(neptune_hip::ops::EulerAxpy<T, 1>{dt}, &g, ptrs, out.dev,
+                                                                                         sc.stream(), launch_override());
+    if (rc != NEPTUNE_HIP_OK) die(sc.name(), "neptune_ir.time_advance: axpy launch rejected");
+  }
+  if (direct) sc.mark_dirty(*dest);
+  return out;
+}
+
 // neptune_ir.reduce {kind = "sum"} (DataflowLowering.cpp:589-698): blocking, result on the host
 // slab mode: this rank's partial sum over its owned planes (the caller adds the ranks' results)
 inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, int dtype) {
@@ -577,7 +700,6 @@ inline double run_reduce_sum(Scope& sc, const Val& src, const Box* bounds_decl, 
     // a whole-buffer sum of a field with leading batch dimensions: the same fixed tree over the flat buffer
     if (bounds) {
       // one rank-3 box sum per leading index of the reduced box, added up in index order
-      if (sc.slab()) die(sc.name(), "neptune_ir.reduce on a temp of rank > 3 is not lowered in slab mode");
       const Box s3 = last3(src.box), b3 = last3(*bounds);
       for_each_lead(*bounds, [&](const int64_t* idx) {
         const int64_t so = lead_offset_cells(src.box, idx);

@@ -150,6 +150,18 @@ def main():
     _, elem, nin, acc, _, _ = mh.CASES["radius4_2d"]
     r4 = mh.module_text((40, 256), elem, nin, acc, [4, 4], [36, 252])
     ok["geom_entry_2d_radius4"] = run_geom_entry_case(rank, world, r4, "resid", (40, 256), 4, 1, 2)
+    # rank 4: dim 0 (the slab axis) as a batch dimension of a 3-D operator (no offsets along it: every rank runs its own
+    # leading indices) and as the first dimension of a stencil in FOUR dimensions (the rank-generic kernel reads the ghost
+    # planes); the operator itself and an explicit time step of it
+    import test_batched_gpu as tb
+    f4 = tb.FIXTURE.read_text().replace("ub = [3, 10, 12, 256]", "ub = [13, 10, 12, 256]").replace("ub = [3, 9, 11, 255]", "ub = [12, 9, 11, 255]")
+    step1 = tb.STEP4.replace("@RHS", "@lapc").replace('    %u2 = neptune_ir.time_advance %u1, %dt {method = 0 : i32, rhs = @RHS} : !t, f64 -> !t\n'.replace("@RHS", "@lapc"), "").replace("%u2", "%u1")
+    batched4 = f4[:f4.rindex("}")] + step1
+    nd4 = batched4.replace("%a[0, -1, 0, 0]", "%a[-1, 0, 0, 0]").replace("%a[0, 1, 0, 0]", "%a[1, 0, 0, 0]")
+    ok["rank4_batched_entry"] = run_case(rank, world, batched4, "entry", (13, 10, 12, 256), 2)
+    ok["rank4_batched_step"] = run_case(rank, world, batched4, "step", (13, 10, 12, 256), 2)
+    ok["rank4_stencil4d_entry"] = run_case(rank, world, nd4, "entry", (13, 10, 12, 256), 2)
+    ok["rank4_stencil4d_step"] = run_case(rank, world, nd4, "step", (13, 10, 12, 256), 2)
     # reduce: every rank sums its owned planes, the partial sums are added
     n0, n1 = 37, 256
     red = compile_shared(SUMSQ.format(n0=n0, n1=n1, m0=n0 - 1, m1=n1 - 1))
