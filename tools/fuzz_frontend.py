@@ -30,7 +30,10 @@ def asan_build(directory: Path) -> Path:
 def corpus(generator_seeds=range(7000, 7030)):
     import test_fuzz_gpu as fz
     files = glob.glob(str(REPO / "tests/**/*.mlir"), recursive=True) + glob.glob("/root/reference/test/**/*.mlir", recursive=True)
-    return [Path(f).read_text() for f in sorted(files)] + [fz.gen_module(s)[0] for s in generator_seeds]
+    import test_batched_gpu as tb
+    import test_ownbox_gpu as ob
+    extra = [ob.case_text(n) for n in ob.CASES] + [tb.rank5_text(), tb.stencil4d_text(), tb.stencil5d_text()] + list(tb.step4_texts().values())
+    return [Path(f).read_text() for f in sorted(files)] + [fz.gen_module(s)[0] for s in generator_seeds] + extra
 
 
 def mutate(rng, s):
