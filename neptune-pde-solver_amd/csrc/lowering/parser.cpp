@@ -178,6 +178,17 @@ struct Parser {
       accept(",");
     }
     if (!has_lb || !has_ub || b.lb.size() != b.ub.size()) { diag.fail(peek().line, "bounds lb/ub rank mismatch"); return false; }
+    // coordinates far beyond any buffer would overflow the extent arithmetic downstream (ub - lb, products of extents)
+    const int64_t lim = (int64_t)1 << 40;
+    long double cells = 1.0L;
+    for (size_t d = 0; d < b.lb.size(); ++d) {
+      if (b.lb[d] < -lim || b.lb[d] > lim || b.ub[d] < -lim || b.ub[d] > lim) {
+        diag.fail(peek().line, "bounds coordinate outside the supported range [-2^40, 2^40]");
+        return false;
+      }
+      if (b.ub[d] > b.lb[d]) cells *= (long double)(b.ub[d] - b.lb[d]);
+    }
+    if (cells > 4.0e18L) { diag.fail(peek().line, "bounds describe more than 2^62 cells"); return false; }
     return ok();
   }
   bool parse_attr_value(AttrValue& a) {

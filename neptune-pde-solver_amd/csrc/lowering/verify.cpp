@@ -116,6 +116,8 @@ struct Verifier {
           diag.fail(op.line, "'neptune_ir.access' op offsets rank must match apply bounds rank");
           return false;
         }
+        for (int64_t off : op.offsets)
+          if (off < -(1 << 20) || off > (1 << 20)) { diag.fail(op.line, "'neptune_ir.access' op offset outside the supported range [-2^20, 2^20]"); return false; }
         if (op.types.size() != 2 || op.types[0] != in) { diag.fail(op.line, "'neptune_ir.access' op operand type does not match its declared type"); return false; }
         if (!op.types[1].is_scalar() || op.types[1].elem != in.elem) {
           diag.fail(op.line, "'neptune_ir.access' op result type must equal input Temp element type");

@@ -597,3 +597,19 @@ def test_every_committed_module_cross_compiles_for_gfx950(tmp_path, monkeypatch)
     logs = "".join(p.read_text()[:1500] for p in tmp_path.glob("*.log") if "error" in p.read_text())
     assert not missing, f"did not compile: {missing}\n{logs}"
     assert len(built) == len(set(texts))
+
+
+def test_absurd_bounds_and_offsets_are_refused_before_any_arithmetic_overflows():
+    """found by the sanitizer fuzz of round 3 (tools/fuzz_frontend.py): a bounds coordinate of 2^63 made `ub - lb` overflow in
+    the emitter; coordinates beyond 2^40, boxes beyond 2^62 cells and access offsets beyond 2^20 are diagnosed by the front end"""
+    from neptune_hip import lowering
+    text = (helpers.FIXTURE_DIR / "apply-2d-5pt.mlir").read_text()
+    lowering.verify(text)
+    with pytest.raises(lowering.LoweringError, match=r"bounds coordinate outside the supported range \[-2\^40, 2\^40\]"):
+        lowering.verify(text.replace("ub = [1024, 1024]", "ub = [9223372036854775808, 1024]"))
+    with pytest.raises(lowering.LoweringError, match=r"bounds coordinate outside the supported range"):
+        lowering.verify(text.replace("lb = [0, 0]", "lb = [-99999999999999, 0]", 1))
+    with pytest.raises(lowering.LoweringError, match="bounds describe more than 2\\^62 cells"):
+        lowering.verify(text.replace("ub = [1024, 1024]", "ub = [1099511627776, 1099511627776]"))
+    with pytest.raises(lowering.LoweringError, match=r"offset outside the supported range \[-2\^20, 2\^20\]"):
+        lowering.verify(text.replace("[-1, 0]", "[-99999999999, 0]"))
