@@ -655,6 +655,38 @@ def main():
                 dist.destroy_process_group()
             sys.exit(5)
 
+    # ---- a plain copy of the same field, same process, same clocks: the measured ceiling the roofline fraction sits under ----
+    # ("also report vs the measured-copy ceiling"; outside the timed region, N = 1 only)
+    copy_ceiling = None
+    if world == 1 and emu is None and not args.no_verify:
+        dog.stage("copy ceiling", 120)
+        src_t, dst_t = bufs[0].tensor, bufs[1].tensor
+        nbytes2 = 2.0 * src_t.numel() * src_t.element_size()
+        dt_code = _capi.F64 if esize == 8 else _capi.F32
+
+        def timed(fn, reps=10):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        cur = int(torch.cuda.current_stream().cuda_stream)
+        cands = {"torch tensor.copy_ (hipMemcpyAsync device to device)": timed(lambda: dst_t.copy_(src_t)),
+                 "neptune_hip_store_full (what an un-elided whole-field neptune_ir.store costs)":
+                     timed(lambda: lib.neptune_hip_store_full(dt_code, src_t.data_ptr(), dst_t.data_ptr(), src_t.numel(), cur or None))}
+        # the library's 16-byte-per-lane streaming copies (grid-stride; 1-8 loads in flight per lane; plain / non-temporal)
+        for mode in range(lib.neptune_hip_copy_mode_count()):
+            cands[f"neptune_hip_time_copy mode {mode} (16 B per lane streaming copy kernel)"] = \
+                lib.neptune_hip_time_copy(dst_t.data_ptr(), src_t.data_ptr(), src_t.numel() * src_t.element_size(), cur or None, mode, 3, 10)
+        how, ms_c = min(cands.items(), key=lambda kv: kv[1])
+        copy_ceiling = {"GBps": nbytes2 / ms_c / 1e6, "ms": ms_c, "how": how + ", 10 launches after 3 warm-ups, this process, after the timed region",
+                        "all_ms": {k.split(" (")[0]: round(v, 4) for k, v in cands.items()}}
+        dog.done()
+
     # ---- the other single-GPU BASELINE configurations ------------------------------------------------------------------
     configs = None
     if extra:
@@ -741,6 +773,8 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kern_ms,
                 "per": "launch (whole field)" if world == 1 else "step on rank 0 (interior + edge launches)",
+                "copy_ceiling": copy_ceiling,
+                "frac_of_copy": (achieved / copy_ceiling["GBps"]) if copy_ceiling else None,
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -717,6 +717,24 @@ int neptune_hip_store_full(int dtype, const void* src, void* dst, int64_t count,
   if (dtype != NEPTUNE_HIP_F64 && dtype != NEPTUNE_HIP_F32) return NEPTUNE_HIP_EINVAL;
   const size_t bytes = (size_t)count * (dtype == NEPTUNE_HIP_F64 ? 8 : 4);
   if (bytes == 0 || src == dst) return NEPTUNE_HIP_OK;
+  // 16-byte-aligned device buffers: the streaming copy kernel (one 16-byte load per lane, non-temporal store: 6.4 TB/s on a
+  // 1024^3 fp64 field against 5.1 for hipMemcpyAsync, bench.py roofline.copy_ceiling); anything else, and the last few
+  // bytes, through the runtime's copy
+  const bool aligned = ((uintptr_t)src | (uintptr_t)dst) % 16 == 0;
+  const int64_t n16 = aligned ? (int64_t)(bytes / 16) : 0;
+  if (n16 > 0) {
+    ensure_init();
+    const int64_t blocks = (n16 + 255) / 256;
+    if (blocks <= 0x7fffffffLL) {
+      hipLaunchKernelGGL((neptune_copy16_unrolled<1, false, true>), dim3((uint32_t)blocks), dim3(256), 0, as_stream(stream),
+                         (const u32x4*)src, (u32x4*)dst, n16);
+      NEPTUNE_HIP_CHECK(hipGetLastError());
+      const size_t done = (size_t)n16 * 16;
+      if (done < bytes)
+        NEPTUNE_HIP_CHECK(hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyDeviceToDevice, as_stream(stream)));
+      return NEPTUNE_HIP_OK;
+    }
+  }
   NEPTUNE_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
   return NEPTUNE_HIP_OK;
 }

@@ -198,6 +198,20 @@ def test_store_full_and_box(nh):
     nh.apply.store(fs, f2)
     nh.torch.cuda.synchronize()
     assert bits_equal(f2.numpy(), s)
+    # whole-buffer stores of every length around the 16-byte words of the streaming copy kernel (tail bytes, misaligned
+    # buffers: the runtime's copy), the destination's neighbours untouched
+    torch = nh.torch
+    for dt, code in ((torch.float32, nh.capi.F32), (torch.float64, nh.capi.F64)):
+        for n in (1, 2, 3, 4, 5, 7, 255, 1024, 1027, 4099, 70001):
+            for shift in (0, 1):
+                src = torch.arange(n + 8, dtype=dt, device="cuda") * 0.5 + 1.0
+                dst = torch.full((n + 8,), -1.0, dtype=dt, device="cuda")
+                a, b = src[shift:shift + n], dst[4 + shift:4 + shift + n]
+                assert nh.lib.neptune_hip_store_full(code, a.data_ptr(), b.data_ptr(), n, None) == 0
+                torch.cuda.synchronize()
+                want_d = torch.full((n + 8,), -1.0, dtype=dt, device="cuda")
+                want_d[4 + shift:4 + shift + n] = a
+                assert torch.equal(dst, want_d), (dt, n, shift)
     # 3-D f32 box, empty box, and a box leaving the destination
     s3 = helpers.hash_field((4, 6, 10), np.float32, seed=4)
     f3 = nh.fields.DeviceField.from_numpy(s3)
