@@ -177,6 +177,18 @@ int vec_update(int dtype, int64_t n, double a, const void* x, void* y, void* str
   // the kernel reads x and writes y through __restrict__ pointers: overlapping ranges would be undefined behaviour
   if (overlaps(x, (size_t)n * (dtype == NEPTUNE_HIP_F64 ? 8 : 4), y, (size_t)n * (dtype == NEPTUNE_HIP_F64 ? 8 : 4))) return NEPTUNE_HIP_EINVAL;
   ensure_init();
+  if (((uintptr_t)x | (uintptr_t)y) % 16 == 0) {   // 16-byte vectors, exact grid
+    const int vk = dtype == NEPTUNE_HIP_F64 ? 2 : 4;
+    const int64_t nv = n / vk, vblocks = nv > 0 ? (nv + 255) / 256 : 1;
+    if (vblocks <= 0x7fffffffLL) {
+      if (dtype == NEPTUNE_HIP_F64)
+        hipLaunchKernelGGL((neptune_vec_update_v<double, XPAY>), dim3((uint32_t)vblocks), dim3(256), 0, as_stream(stream), n, a, (const double*)x, (double*)y);
+      else
+        hipLaunchKernelGGL((neptune_vec_update_v<float, XPAY>), dim3((uint32_t)vblocks), dim3(256), 0, as_stream(stream), n, (float)a, (const float*)x, (float*)y);
+      NEPTUNE_HIP_CHECK(hipGetLastError());
+      return NEPTUNE_HIP_OK;
+    }
+  }
   const int64_t want = (n + 255) / 256;
   const uint32_t blocks = (uint32_t)(want < 256 * 32 ? want : 256 * 32);
   if (dtype == NEPTUNE_HIP_F64)

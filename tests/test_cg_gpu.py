@@ -152,3 +152,31 @@ def test_c_caller_in_the_shape_of_the_snes_residual_thunk(built_libs, tmp_path, 
     assert helpers.bits_equal(got[0], (ins[0] - ins[1])[0])            # the rim branch: x - up
     if mode == "device":
         assert "pool_cached_bytes 0" in p.stdout                       # nothing was staged through a device shadow
+
+
+@pytest.mark.gpu
+def test_vector_updates_match_numpy_for_every_length_and_alignment(built_libs):
+    """neptune_hip_axpy / _xpay: y + a*x and x + a*y with two roundings (no FMA), 16-byte vector form on aligned buffers with
+    the last n % VK elements through one lane, scalar form on misaligned ones -- bit for bit what numpy computes"""
+    import numpy as np
+    import torch
+    from neptune_hip import _capi
+    lib = _capi.load()
+    lib.neptune_hip_init(0)
+    rng = np.random.default_rng(9)
+    for npdt, tdt, code in ((np.float64, torch.float64, _capi.F64), (np.float32, torch.float32, _capi.F32)):
+        for n in (1, 2, 3, 4, 5, 7, 8, 255, 256, 257, 1023, 4099, 100003):
+            for shift in (0, 1):
+                x = rng.standard_normal(n + shift).astype(npdt)
+                y = rng.standard_normal(n + shift).astype(npdt)
+                a = npdt(0.37)
+                dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+                assert lib.neptune_hip_axpy(code, n, float(a), dx[shift:].data_ptr(), dy[shift:].data_ptr(), None) == 0
+                want = y.copy()
+                want[shift:] = y[shift:] + a * x[shift:]
+                assert np.array_equal(dy.cpu().numpy().view(np.uint8), want.view(np.uint8)), (npdt, n, shift, "axpy")
+                dy2 = torch.from_numpy(y).cuda()
+                assert lib.neptune_hip_xpay(code, n, dx[shift:].data_ptr(), float(a), dy2[shift:].data_ptr(), None) == 0
+                want2 = y.copy()
+                want2[shift:] = x[shift:] + a * y[shift:]
+                assert np.array_equal(dy2.cpu().numpy().view(np.uint8), want2.view(np.uint8)), (npdt, n, shift, "xpay")
