@@ -16,6 +16,7 @@
 #pragma once
 #include <array>
 #include <map>
+#include <math.h>
 #include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
@@ -779,11 +780,14 @@ inline neptune_hip_launch_cfg_t tune_apply(const Body& body, const neptune_hip_a
     float first = 0, ms = 0;
     NEPTUNE_HIP_CHECK(hipEventElapsedTime(&first, e0, e1));
     if (best_ms > 0 && first > 1.4f * best_ms) return first;
-    for (int r = 0; r < 3; ++r) launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c);
+    // repetitions for about 4 ms of launches, 3 to 20: the tiles of a 0.2-0.4 ms launch lie within 2-3 % of each other, which
+    // three repetitions do not resolve (the same geometry then gets different tiles on different boxes)
+    const int reps = first > 0.f ? (int)fminf(20.f, fmaxf(3.f, ceilf(4.f / first))) : 3;
+    for (int r = 0; r < reps; ++r) launch_apply_impl<Body, T, RANK, NIN, FP>(body, g, in, out, stream, &c);
     NEPTUNE_HIP_CHECK(hipEventRecord(e2, stream));
     NEPTUNE_HIP_CHECK(hipEventSynchronize(e2));
     NEPTUNE_HIP_CHECK(hipEventElapsedTime(&ms, e1, e2));
-    return ms / 3.f;
+    return ms / (float)reps;
   };
   auto try_cfg = [&](const neptune_hip_launch_cfg_t& c) {
     const float ms = time_cfg(c);

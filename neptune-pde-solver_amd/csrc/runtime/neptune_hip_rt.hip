@@ -131,6 +131,8 @@ int autotune_launches(L&& launch, bool march_planned, int rank, int nv, hipStrea
   *best = probe;
   double best_t = time_launches(launch, st, &probe, 2, reps);
   if (best_t < 0) return (int)best_t;
+  // short launches need more repetitions to tell tiles 2-3 % apart: at least ~4 ms of launches per candidate
+  if (best_t > 0 && best_t * reps < 4.0) reps = (int)(4.0 / best_t) + 1 < 24 ? (int)(4.0 / best_t) + 1 : 24;
   struct Cand { neptune_hip_launch_cfg_t cfg; double t; };
   std::vector<Cand> cands;
   cands.push_back({probe, best_t});
