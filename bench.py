@@ -923,6 +923,12 @@ def run_config(name, nh_apply, fields, slab_mod, lib, _capi, torch, chain=1, ste
     if chain == 1:
         res["variant"] = lib.neptune_hip_march_variant_name(nd, int(launched.variant)).decode() if int(launched.kernel) == _capi.KERNEL_MARCH else ""
         res["chunk"] = int(launched.chunk)
+        # a plain copy of a field of this size, same process: the ceiling under this line (the faster of the library's two best
+        # streaming-copy flavours, 20 launches each)
+        nbytes = cells * esize
+        copy_ms = min(lib.neptune_hip_time_copy(b.ptr, a.ptr, int(nbytes), st, mode, 3, 20) for mode in (3, 5))
+        res["copy_GBps"] = 2.0 * nbytes / copy_ms / 1e6
+        res["frac_of_copy"] = gbps / res["copy_GBps"]
     else:
         res["variant"], res["chunk"] = f"apply_march2 NS={chain}", None
         res["note"] = "frac counts 2 N sizeof(T) per STEP; the kernel moves ~2.35 field passes per three steps, so values above 1 are expected"
