@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CHECK(e)                                                                        \
@@ -23,6 +24,11 @@
 typedef double V2 __attribute__((ext_vector_type(2)));
 constexpr int kWave = 64;
 
+static uint32_t xcd_remap_host(uint32_t b, uint32_t nb) {
+  const uint32_t q = nb / 8, r = nb % 8;
+  const uint32_t xcd = b % 8, pos = b / 8;
+  return xcd < r ? xcd * (q + 1) + pos : r * (q + 1) + (xcd - r) * q + pos;
+}
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t nb) {
   const uint32_t q = nb / 8, r = nb % 8;
   const uint32_t xcd = b % 8, pos = b / 8;
@@ -44,6 +50,7 @@ struct P3 {
   int32_t N0, N1, N2, chunk;
   uint32_t nJ, nK, nC;
   int32_t order;  // 0: K tiles fastest, then J, then chunks (the march kernel's numbering); 1: J fastest, K, chunks; 2: chunks fastest
+  uint64_t* ts;   // timeline mode: per workgroup {start, first store issued, end} on the 100 MHz wall clock (null: off)
 };
 
 // the march kernel's traversal without its stencil: SYNC adds the per-plane workgroup barrier, REMAP the XCD-aware
@@ -55,6 +62,7 @@ __global__ __launch_bounds__(kWave* WJ* WK) void march_copy(P3 P) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wj = w / WK, wk = w % WK;
   const uint32_t v = REMAP ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+  if (P.ts && threadIdx.x == 0) P.ts[3 * blockIdx.x] = wall_clock64();
   uint32_t kt, jt, ct;
   if (P.order == 0) { kt = v % P.nK; const uint32_t t = v / P.nK; jt = t % P.nJ; ct = t / P.nJ; }
   else if (P.order == 1) { jt = v % P.nJ; const uint32_t t = v / P.nJ; kt = t % P.nK; ct = t / P.nK; }
@@ -109,6 +117,11 @@ __global__ __launch_bounds__(kWave* WJ* WK) void march_copy(P3 P) {
       constexpr int ph = phc;
       if (i + ph < ie) step(i + ph, phc);
     });
+    if (P.ts && threadIdx.x == 0 && i == ib) P.ts[3 * blockIdx.x + 1] = wall_clock64();
+  }
+  if (P.ts && threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);   // this wave's stores have left
+    P.ts[3 * blockIdx.x + 2] = wall_clock64();
   }
 }
 
@@ -401,6 +414,60 @@ static void run_march(const char* name, const double* in, double* out, int N0, i
   fflush(stdout);
 }
 
+// timeline of `launches` back-to-back launches of one march_copy shape: when workgroups start, issue their first stores and end
+// (100 MHz wall clock, all relative to the first start of each launch), and the gap to the next launch's first start
+template <int RJ, int WJ, int WK, int PF>
+static void run_timeline(const char* name, const double* in, double* out, int N0, int N1, int N2, int chunk, int launches, int order = 0) {
+  P3 P{in, out, N0, N1, N2, chunk, (uint32_t)((N1 + WJ * RJ - 1) / (WJ * RJ)), (uint32_t)((N2 + WK * 128 - 1) / (WK * 128)),
+       (uint32_t)((N0 + chunk - 1) / chunk), order, nullptr};
+  const uint32_t blocks = P.nJ * P.nK * P.nC;
+  uint64_t* ts;
+  CHECK(hipMalloc(&ts, (size_t)launches * blocks * 3 * 8));
+  auto kern = march_copy<RJ, WJ, WK, PF, true, true, true, false>;
+  for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWave * WJ * WK), 0, 0, P);   // warm
+  for (int l = 0; l < launches; ++l) {
+    P.ts = ts + (size_t)l * blocks * 3;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWave * WJ * WK), 0, 0, P);
+  }
+  CHECK(hipDeviceSynchronize());
+  std::vector<uint64_t> h((size_t)launches * blocks * 3);
+  CHECK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+  printf("timeline %s chunk=%d order=%d wgs=%u (us; 100 MHz clock)\n", name, chunk, order, blocks);
+  uint64_t prev_end = 0;
+  for (int l = 0; l < launches; ++l) {
+    const uint64_t* t = h.data() + (size_t)l * blocks * 3;
+    uint64_t s0 = ~0ull, s1 = 0, f0 = ~0ull, f1 = 0, e0 = ~0ull, e1 = 0;
+    double esum = 0;
+    for (uint32_t b = 0; b < blocks; ++b) {
+      s0 = t[3 * b] < s0 ? t[3 * b] : s0; s1 = t[3 * b] > s1 ? t[3 * b] : s1;
+      f0 = t[3 * b + 1] < f0 ? t[3 * b + 1] : f0; f1 = t[3 * b + 1] > f1 ? t[3 * b + 1] : f1;
+      e0 = t[3 * b + 2] < e0 ? t[3 * b + 2] : e0; e1 = t[3 * b + 2] > e1 ? t[3 * b + 2] : e1;
+    }
+    for (uint32_t b = 0; b < blocks; ++b) esum += (double)(t[3 * b + 2] - s0);
+    printf("  launch %2d: starts 0..%.2f  first step done %.2f..%.2f  ends %.2f..%.2f (mean %.2f)  span %.2f  gap since previous end %.2f\n", l,
+           (s1 - s0) / 100.0, (f0 - s0) / 100.0, (f1 - s0) / 100.0, (e0 - s0) / 100.0, (e1 - s0) / 100.0, esum / blocks / 100.0,
+           (e1 - s0) / 100.0, prev_end ? (double)((int64_t)(s0 - prev_end)) / 100.0 : 0.0);
+    prev_end = e1;
+    if (l == launches - 1) {
+      // who finishes late?  mean end per XCD (blockIdx % 8) and per chunk index (virtual id / tiles)
+      double xs[8] = {0}, xn[8] = {0};
+      std::vector<double> cs(P.nC, 0.0), cn(P.nC, 0.0);
+      for (uint32_t b = 0; b < blocks; ++b) {
+        const double e = (double)(t[3 * b + 2] - s0) / 100.0;
+        xs[b % 8] += e; xn[b % 8] += 1;
+        const uint32_t v = xcd_remap_host(b, blocks), ct = P.order == 2 ? v % P.nC : v / (P.nJ * P.nK);
+        cs[ct] += e; cn[ct] += 1;
+      }
+      printf("    mean end per XCD:  ");
+      for (int x = 0; x < 8; ++x) printf(" %.1f", xs[x] / (xn[x] > 0 ? xn[x] : 1));
+      printf("\n    mean end per chunk:");
+      for (uint32_t c = 0; c < P.nC; ++c) printf(" %.1f", cs[c] / (cn[c] > 0 ? cn[c] : 1));
+      printf("\n");
+    }
+  }
+  CHECK(hipFree(ts));
+}
+
 // short-lived workgroups (256 lanes) in linear order: a workgroup copies `nseg` segments of `seg16` 16-byte words at
 // stride `stride16`; G = stride16 / seg16 consecutive workgroups interleave inside a super-block of nseg * stride16
 // words, so the union over the grid is the whole buffer exactly once
@@ -429,6 +496,15 @@ int main(int argc, char** argv) {
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
   const double bytes2 = 2.0 * n * 8;
+  if (argc >= 6 && !strcmp(argv[5], "timeline")) {
+    time_ms([&] { hipLaunchKernelGGL((lin_copy<1, true>), dim3((n16 + 255) / 256), dim3(256), 0, 0, (const V2*)a, (V2*)b, n16); }, 0, 200);
+    run_timeline<4, 8, 1, 1>("rj4_wj8_wk1_pf1", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6);
+    run_timeline<4, 8, 1, 2>("rj4_wj8_wk1_pf2", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6);
+    run_timeline<4, 4, 2, 2>("rj4_wj4_wk2_pf2", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6);
+    run_timeline<4, 8, 1, 1>("rj4_wj8_wk1_pf1", a, b, N0, N1, N2, N0 / 16 > 0 ? N0 / 16 : 1, 6);
+    run_timeline<4, 8, 1, 1>("rj4_wj8_wk1_pf1 chunks fastest (every XCD works on every chunk)", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6, 2);
+    return 0;
+  }
   // ramp the clocks
   time_ms([&] { hipLaunchKernelGGL((lin_copy<1, true>), dim3((n16 + 255) / 256), dim3(256), 0, 0, (const V2*)a, (V2*)b, n16); }, 0, 40);
   for (int pass = 0; pass < 2; ++pass) {
