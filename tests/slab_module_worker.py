@@ -127,6 +127,23 @@ def main():
     ok = {}
     shape = (24, 12, 256)
     text = make_stencil_mlir.stencil_module("3d7", list(shape), time_step=0.125)
+    if rank == 0:
+        # every module of this file side by side on host threads before the first case (rank 0 compiles, the others load)
+        import test_batched_gpu as tb0
+        import test_multihalo_gpu as mh0
+        f40 = tb0.FIXTURE.read_text().replace("ub = [3, 10, 12, 256]", "ub = [13, 10, 12, 256]").replace("ub = [3, 9, 11, 255]", "ub = [12, 9, 11, 255]")
+        st0 = tb0.STEP4.replace("@RHS", "@lapc").replace('    %u2 = neptune_ir.time_advance %u1, %dt {method = 0 : i32, rhs = @lapc} : !t, f64 -> !t\n', "").replace("%u2", "%u1")
+        b40 = f40[:f40.rindex("}")] + st0
+        pre = [text, (REPO / "tests/mlir_tests/time_stepping/explicit-twostage-3d.mlir").read_text(),
+               make_stencil_mlir.stencil_module("2d5", [40, 512], time_step=0.0625),
+               (REPO / "tests/mlir_tests/conversion_tests/apply-3d-13pt.mlir").read_text(),
+               mh0.module_text((24, 10, 128), *mh0.CASES["swe3d_two_stars"][1:4], [1, 1, 1], [23, 9, 127]),
+               mh0.module_text((24, 14, 128), *mh0.CASES["radius3_3d"][1:4], [3, 3, 3], [21, 11, 125]),
+               mh0.module_text((40, 256), *mh0.CASES["radius4_2d"][1:4], [4, 4], [36, 252]),
+               b40, b40.replace("%a[0, -1, 0, 0]", "%a[-1, 0, 0, 0]").replace("%a[0, 1, 0, 0]", "%a[1, 0, 0, 0]"),
+               SUMSQ.format(n0=37, n1=256, m0=36, m1=255)]
+        helpers.prefetch_modules(pre)
+    dist.barrier()
     ok["entry"] = run_case(rank, world, text, "entry", shape, 3)
     ok["fused_step"] = run_case(rank, world, text, "step", shape, 3)
     # pointwise apply -> stencil apply -> axpy: the first result is computed on the ghost planes too, so
