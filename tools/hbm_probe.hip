@@ -468,6 +468,158 @@ static void run_timeline(const char* name, const double* in, double* out, int N0
   CHECK(hipFree(ts));
 }
 
+// ---- pairs of workgroups meeting in the middle (what DESIGN.md section 8 item 3 proposes for the march kernel), tried on the copy ----
+// Chunks 2m and 2m+1 of a tile form one plane range; the even workgroup marches UP from its bottom, the odd one DOWN from its top.
+// mode 0: they meet at the static middle.  mode 1: when a workgroup has done 70 % of its static share it publishes how long that took;
+// the second of the pair to get there knows both rates, splits the range in their proportion and publishes the split (one CAS); the
+// first adopts it when it sees it (wave 0 polls one word per step, LDS carries it to the other waves behind the step's barrier) and
+// falls back to the static middle if the word is still empty a few planes before it.  Nobody ever waits for anybody.
+struct PairCtl { unsigned long long first_ticks; unsigned int n_up_plus1; unsigned int pad; };
+template <int RJ, int WJ, int PF>
+__global__ __launch_bounds__(kWave* WJ) void march_pair_copy(P3 P, PairCtl* ctl, int mode) {
+  __shared__ int s_n;
+  const int lane = threadIdx.x & 63;
+  const int wj = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t v = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned long long t_start = wall_clock64();
+  if (P.ts && threadIdx.x == 0) P.ts[3 * blockIdx.x] = t_start;
+  const uint32_t kt = v % P.nK, tt = v / P.nK, jt = tt % P.nJ, ct = tt / P.nJ;
+  const uint32_t seg = ct / 2, role = ct % 2;
+  const int32_t sb = (int32_t)seg * 2 * P.chunk;
+  const int32_t se = sb + 2 * P.chunk < P.N0 ? sb + 2 * P.chunk : P.N0;
+  const int32_t S = se - sb, n_up_static = P.chunk < S ? P.chunk : S;
+  const int32_t n_static = role == 0 ? n_up_static : S - n_up_static;
+  PairCtl* c = ctl + ((size_t)seg * P.nJ * P.nK + (size_t)jt * P.nK + kt);
+  const int32_t j0 = (int32_t)(jt * (WJ * RJ)) + wj * RJ;
+  const int32_t k0 = (int32_t)(kt * 128u) + lane * 2;
+  const bool ok = j0 < P.N1 && k0 < P.N2;
+  const int64_t plane = (int64_t)P.N1 * P.N2;
+  const int64_t base = ok ? (int64_t)j0 * P.N2 + k0 : 0;
+  auto phys = [&](int32_t t) { return role == 0 ? sb + t : se - 1 - t; };
+  if (threadIdx.x == 0) s_n = n_static;
+  __syncthreads();
+  int32_t n_cur = n_static;
+  const int32_t t0 = (n_static * 7) / 10;
+  bool decided = mode == 0 || S < 16;
+  V2 nxt[PF][RJ];
+  sfor<PF>([&](auto dc) {
+    constexpr int d = dc;
+    int32_t ip = phys(d < n_static ? d : (n_static > 0 ? n_static - 1 : 0));
+    ip = ip < 0 ? 0 : (ip >= P.N0 ? P.N0 - 1 : ip);
+    sfor<RJ>([&](auto rc) {
+      constexpr int r = rc;
+      nxt[d][r] = *reinterpret_cast<const V2*>(P.in + (int64_t)ip * plane + base + (int64_t)r * P.N2);
+    });
+  });
+  auto step = [&](int32_t t, auto slot_c) {
+    constexpr int slot = slot_c;
+    V2 cur[RJ];
+    sfor<RJ>([&](auto rc) { constexpr int r = rc; cur[r] = nxt[slot][r]; });
+    if (threadIdx.x == 0 && !decided) {
+      // wave 0, one lane: the pair's bookkeeping
+      int32_t n_up = -1;
+      if (t == t0) {
+        unsigned long long el = wall_clock64() - t_start;
+        el = el ? el : 1;
+        const unsigned long long old = atomicCAS(&c->first_ticks, 0ull, el);
+        if (old != 0) {   // second of the pair: split the range in the ratio of the two rates
+          const double share_first = (double)el / (double)(old + el);       // the first one was faster: it gets the larger share
+          int32_t n_first = (int32_t)(share_first * S + 0.5);
+          const int32_t lo = t0 + PF + 3, hi = S - (t0 + PF + 3);
+          n_first = n_first < lo ? lo : (n_first > hi ? hi : n_first);
+          const int32_t want_up = role == 0 ? S - n_first : n_first;          // I am the second; the first has the other role
+          const unsigned int prev = atomicCAS(&c->n_up_plus1, 0u, (unsigned int)want_up + 1u);
+          n_up = prev ? (int32_t)prev - 1 : want_up;
+        }
+      } else if (t > t0) {
+        const unsigned int seen = __hip_atomic_load(&c->n_up_plus1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen) n_up = (int32_t)seen - 1;
+        else if (t + PF + 3 >= n_static) {   // nothing yet and the static middle is near: settle on it
+          const unsigned int prev = atomicCAS(&c->n_up_plus1, 0u, (unsigned int)n_up_static + 1u);
+          n_up = prev ? (int32_t)prev - 1 : n_up_static;
+        }
+      }
+      if (n_up >= 0) { s_n = role == 0 ? n_up : S - n_up; decided = true; }
+    }
+    __syncthreads();
+    n_cur = s_n;
+    if (t + PF < n_cur) {
+      int32_t ip = phys(t + PF);
+      sfor<RJ>([&](auto rc) {
+        constexpr int r = rc;
+        nxt[slot][r] = *reinterpret_cast<const V2*>(P.in + (int64_t)ip * plane + base + (int64_t)r * P.N2);
+      });
+    }
+    if (ok) {
+      const int32_t op = phys(t);
+      sfor<RJ>([&](auto rc) {
+        constexpr int r = rc;
+        __builtin_nontemporal_store(cur[r], reinterpret_cast<V2*>(P.out + (int64_t)op * plane + base + (int64_t)r * P.N2));
+      });
+    }
+  };
+  for (int32_t t = 0; t < n_cur; t += PF) {
+    sfor<PF>([&](auto phc) {
+      constexpr int ph = phc;
+      if (t + ph < n_cur) step(t + ph, phc);
+    });
+  }
+  if (P.ts && threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    P.ts[3 * blockIdx.x + 1] = (unsigned long long)n_cur;
+    P.ts[3 * blockIdx.x + 2] = wall_clock64();
+  }
+}
+
+template <int RJ, int WJ, int PF>
+static void run_pairs(const char* name, const double* in, double* out, int N0, int N1, int N2, int chunk, int mode, int reps) {
+  P3 P{in, out, N0, N1, N2, chunk, (uint32_t)((N1 + WJ * RJ - 1) / (WJ * RJ)), (uint32_t)((N2 + 127) / 128), (uint32_t)((N0 + chunk - 1) / chunk), 0, nullptr};
+  if (P.nC % 2) { printf("pairs: odd number of chunks\n"); return; }
+  const uint32_t blocks = P.nJ * P.nK * P.nC;
+  const size_t nctl = (size_t)(P.nC / 2) * P.nJ * P.nK;
+  PairCtl* ctl;
+  CHECK(hipMalloc(&ctl, nctl * sizeof(PairCtl)));
+  auto kern = march_pair_copy<RJ, WJ, PF>;
+  auto launch = [&] {
+    (void)hipMemsetAsync(ctl, 0, nctl * sizeof(PairCtl), 0);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(kWave * WJ), 0, 0, P, ctl, mode);
+  };
+  const double ms = time_ms(launch, 5, reps);
+  // one more launch with time stamps: spread of the ends, planes done by the up / down halves, and a check of the copy
+  uint64_t* ts;
+  CHECK(hipMalloc(&ts, (size_t)blocks * 3 * 8));
+  CHECK(hipMemset(out, 0, (size_t)N0 * N1 * N2 * 8));
+  P.ts = ts;
+  launch();
+  CHECK(hipDeviceSynchronize());
+  std::vector<uint64_t> h((size_t)blocks * 3);
+  CHECK(hipMemcpy(h.data(), ts, h.size() * 8, hipMemcpyDeviceToHost));
+  uint64_t s0 = ~0ull, e0 = ~0ull, e1 = 0;
+  double esum = 0;
+  int nmin = 1 << 30, nmax = 0;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    s0 = h[3 * b] < s0 ? h[3 * b] : s0;
+    nmin = (int)h[3 * b + 1] < nmin ? (int)h[3 * b + 1] : nmin;
+    nmax = (int)h[3 * b + 1] > nmax ? (int)h[3 * b + 1] : nmax;
+  }
+  for (uint32_t b = 0; b < blocks; ++b) {
+    e0 = h[3 * b + 2] < e0 ? h[3 * b + 2] : e0; e1 = h[3 * b + 2] > e1 ? h[3 * b + 2] : e1;
+    esum += (double)(h[3 * b + 2] - s0);
+  }
+  // the copy must be complete and exact whatever the splits were
+  const size_t n = (size_t)N0 * N1 * N2;
+  std::vector<double> hi(n), ho(n);
+  CHECK(hipMemcpy(hi.data(), in, n * 8, hipMemcpyDeviceToHost));
+  CHECK(hipMemcpy(ho.data(), out, n * 8, hipMemcpyDeviceToHost));
+  const bool same = memcmp(hi.data(), ho.data(), n * 8) == 0;
+  printf("pair_copy %-18s mode=%d (%s) chunk=%d wgs=%u  %8.4f ms %7.1f GB/s   ends %.1f..%.1f us (mean %.1f)  planes per workgroup %d..%d  copy %s\n", name, mode,
+         mode ? "split by measured rates" : "static middle", chunk, blocks, ms, 2.0 * n * 8 / ms / 1e6, (e0 - s0) / 100.0, (e1 - s0) / 100.0,
+         esum / blocks / 100.0, nmin, nmax, same ? "exact" : "WRONG");
+  fflush(stdout);
+  CHECK(hipFree(ts));
+  CHECK(hipFree(ctl));
+}
+
 // short-lived workgroups (256 lanes) in linear order: a workgroup copies `nseg` segments of `seg16` 16-byte words at
 // stride `stride16`; G = stride16 / seg16 consecutive workgroups interleave inside a super-block of nseg * stride16
 // words, so the union over the grid is the whole buffer exactly once
@@ -481,6 +633,11 @@ __global__ __launch_bounds__(256) void seg_copy(const V2* __restrict__ src, V2* 
       const int64_t a = base + s * stride16 + i;
       if (a < n16) __builtin_nontemporal_store(src[a], dst + a);
     }
+}
+
+__global__ __launch_bounds__(256) void fill_index(double* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = (double)i * 0.5 + 1.0;
 }
 
 int main(int argc, char** argv) {
@@ -503,6 +660,18 @@ int main(int argc, char** argv) {
     run_timeline<4, 4, 2, 2>("rj4_wj4_wk2_pf2", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6);
     run_timeline<4, 8, 1, 1>("rj4_wj8_wk1_pf1", a, b, N0, N1, N2, N0 / 16 > 0 ? N0 / 16 : 1, 6);
     run_timeline<4, 8, 1, 1>("rj4_wj8_wk1_pf1 chunks fastest (every XCD works on every chunk)", a, b, N0, N1, N2, N0 / 8 > 0 ? N0 / 8 : 1, 6, 2);
+    return 0;
+  }
+  if (argc >= 6 && !strcmp(argv[5], "pairs")) {
+    time_ms([&] { hipLaunchKernelGGL((lin_copy<1, true>), dim3((n16 + 255) / 256), dim3(256), 0, 0, (const V2*)a, (V2*)b, n16); }, 0, 200);
+    hipLaunchKernelGGL(fill_index, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, 0, a, n);   // every cell different: a misplaced plane shows
+    for (int rep = 0; rep < 3; ++rep) {
+      run_march<4, 8, 1, 1, true, true, true>("rj4_wj8_wk1_pf1 sync (one workgroup per chunk, today)", a, b, N0, N1, N2, N0 / 8, reps, 0, 1);
+      run_pairs<4, 8, 1>("rj4_wj8_pf1", a, b, N0, N1, N2, N0 / 8, 0, reps);
+      run_pairs<4, 8, 1>("rj4_wj8_pf1", a, b, N0, N1, N2, N0 / 8, 1, reps);
+      run_pairs<4, 8, 2>("rj4_wj8_pf2", a, b, N0, N1, N2, N0 / 8, 0, reps);
+      run_pairs<4, 8, 2>("rj4_wj8_pf2", a, b, N0, N1, N2, N0 / 8, 1, reps);
+    }
     return 0;
   }
   // ramp the clocks
