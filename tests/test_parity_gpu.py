@@ -471,3 +471,37 @@ def test_graph_captured_step_loop_equals_chained_launches(nh, kind, shape, steps
         nh.torch.cuda.synchronize()
         assert last is (b if steps % 2 else a)
         assert bits_equal(last.numpy(), want), f"rep {rep}\n" + mismatch_report(last.numpy(), want)
+
+
+@pytest.mark.parametrize("kind", ["2d5", "3d7", "3d27"])
+def test_special_values_denormals_signed_zeros_infinities_nans(nh, kind):
+    """IEEE corner values through every kernel form: subnormal inputs and results are kept (nothing flushes to zero, fp32
+    included), signed zeros and infinities come out bit for bit like the CPU restatement; where the oracle has a NaN the GPU
+    has a NaN (payloads of generated NaNs are the hardware's business on both sides)"""
+    dt = KIND_DTYPE[kind]
+    shape = {"2d5": (40, 520), "3d7": (10, 18, 260), "3d27": (9, 12, 520)}[kind]
+    rng = np.random.default_rng(11)
+    u = helpers.hash_field(shape, dt, seed=8)
+    tiny = np.finfo(dt).tiny
+    specials = np.array([tiny / 8, -tiny / 3, tiny * 1.5, np.nextafter(dt(0), dt(1)), 0.0, -0.0, np.inf, -np.inf, np.nan,
+                         np.finfo(dt).max, -np.finfo(dt).max / 2, tiny], dtype=dt)
+    flat = u.reshape(-1)
+    where = rng.choice(flat.size, size=flat.size // 7, replace=False)
+    flat[where] = specials[rng.integers(0, len(specials), size=where.size)]
+    # a block of nothing but subnormals: results there are subnormal sums, not zeros
+    sl = tuple(slice(2, 6) for _ in shape[:-1]) + (slice(64, 200),)
+    u[sl] = (rng.integers(1, 1000, size=u[sl].shape) * np.nextafter(dt(0), dt(1))).astype(dt)
+    with np.errstate(all="ignore"):
+        want = helpers.oracle_entry(kind, u)
+    assert np.any((np.abs(want[sl]) > 0) & (np.abs(want[sl]) < tiny)), "the fixture should produce subnormal results"
+    rank = len(shape)
+    cfgs = [None, _kernel_cfg(nh, "direct"), _kernel_cfg(nh, "direct-flat")] + \
+           [nh.apply.make_cfg(nh.capi.KERNEL_MARCH, v, c) for v in range(min(8, nh.lib.neptune_hip_march_variant_count(rank))) for c in (0, 3)]
+    ui = np.dtype(dt).itemsize
+    as_int = np.uint64 if ui == 8 else np.uint32
+    for cfg in cfgs:
+        got = _run(nh, kind, u, cfg, prefill=5.0)
+        nan_w, nan_g = np.isnan(want), np.isnan(got)
+        assert np.array_equal(nan_w, nan_g), f"{kind} {cfg and (cfg.kernel, cfg.variant, cfg.chunk)}: NaN positions differ"
+        same = got.view(as_int)[~nan_w] == want.view(as_int)[~nan_w]
+        assert same.all(), f"{kind} {cfg and (cfg.kernel, cfg.variant, cfg.chunk)}: {np.count_nonzero(~same)} finite / infinite / zero cells differ in bits"
