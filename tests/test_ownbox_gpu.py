@@ -130,6 +130,11 @@ def _cases():
                                   [(0, (0, 0)), (1, (0, 0)), (1, (0, 1)), (2, (0, 0))] + [(2, o) for o in star(2, 1)])
     o2n = box((0, 0), (40, 520))
     c["ghosted_radius5_2d_mid_span_f32"] = ("f32", o2n, o2n, [o2n, grow(o2n, (5, 5), (5, 5))], [(0, (0, 0)), (1, (0, 0))] + [(1, o) for o in star(2, 5)])
+    # logical origins near the front end's limit of 2^40: the index arithmetic is 64-bit end to end (the body adds the last index)
+    oh = box((1 << 39, -(1 << 39) + 7), (24, 512))
+    c["huge_origin_2d"] = ("f64", oh, oh, [oh, grow(oh, (1, 1), (1, 1))], [(0, (0, 0)), (1, (0, 0))] + [(1, o) for o in star(2, 1)])
+    oh3 = box((-(1 << 38), 3, (1 << 39) - 100), (6, 9, 260))
+    c["huge_origin_3d_f32"] = ("f32", oh3, oh3, [oh3, grow(oh3, (0, 0, 0), (0, 0, 1))], [(0, (0, 0, 0)), (1, (0, 0, 0)), (1, (0, 0, 1))])
     # rank 1
     o1 = box((0,), (4096,))
     c["staggered_1d"] = ("f64", o1, o1, [o1, grow(o1, (0,), (1,)), grow(o1, (2,), (2,))],
