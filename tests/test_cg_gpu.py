@@ -51,7 +51,8 @@ def test_matrix_free_cg_on_device_matches_the_oracle_driven_solve(built_libs, tm
 
 def test_examples_run(built_libs, tmp_path):
     """the example programs end to end at small sizes (DSL -> jit -> lowered calls, hipGraph step loop, CG, the
-    25-point leapfrog wave step)"""
+    25-point leapfrog wave step, the staggered-grid
+    projection with its face fields in boxes of their own)"""
     import os
     import subprocess
     env = dict(os.environ, NEPTUNE_CACHE_DIR=str(tmp_path))
@@ -65,6 +66,10 @@ def test_examples_run(built_libs, tmp_path):
                           capture_output=True, text=True, timeout=600)
     assert wave.returncode == 0 and "stable: True" in wave.stdout and "('step', 'march')" in wave.stdout, \
         wave.stdout[-1500:] + wave.stderr[-3000:]
+    stag = subprocess.run([sys.executable, str(helpers.REPO / "examples/staggered_projection.py"), "200", "5"], env=env,
+                          capture_output=True, text=True, timeout=600)
+    assert stag.returncode == 0 and "results agree: True" in stag.stdout and "('project', 'march')" in stag.stdout, \
+        stag.stdout[-1500:] + stag.stderr[-3000:]
 
 
 def test_c_krylov_loop_with_device_pointers_through_the_reference_abi(built_libs, tmp_path, monkeypatch):
