@@ -228,7 +228,8 @@ neptune_hip_slab_plan_t* neptune_hip_slab_plan_create(neptune_hip_slab_comm_t* c
     if (!high) greatest = 0;
     if (hipStreamCreateWithPriority(&p->comm_stream, hipStreamNonBlocking, greatest) != hipSuccess ||
         hipEventCreateWithFlags(&p->ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&p->halo_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&p->halo_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->edges_done, hipEventDisableTiming) != hipSuccess) {
       (void)hipGetLastError();
       neptune_hip_slab_plan_destroy(p);
       return fail("cannot create the communication stream / events");
@@ -242,6 +243,7 @@ void neptune_hip_slab_plan_destroy(neptune_hip_slab_plan_t* p) {
   if (p->comm_stream) { (void)hipStreamSynchronize(p->comm_stream); (void)hipStreamDestroy(p->comm_stream); }
   if (p->ready) (void)hipEventDestroy(p->ready);
   if (p->halo_done) (void)hipEventDestroy(p->halo_done);
+  if (p->edges_done) (void)hipEventDestroy(p->edges_done);
   if (p->tev) {
     for (int i = 0; i < slab::Plan::kTimingRing; ++i)
       for (hipEvent_t e : {p->tev[i].x0, p->tev[i].x1, p->tev[i].i0, p->tev[i].i1, p->tev[i].e1})
@@ -298,9 +300,10 @@ int neptune_hip_slab_apply(neptune_hip_slab_plan_t* p, const void* const* in, vo
     if (!in[k]) return NEPTUNE_HIP_EINVAL;
   hipStream_t cs = reinterpret_cast<hipStream_t>(compute_stream);
   const neptune_hip_launch_cfg_t* cfg = p->has_cfg ? &p->cfg : nullptr;
-  auto launch = [&](const neptune_hip_apply_geom_t& g) {
-    return p->fn ? p->fn(&g, in, out, compute_stream, cfg) : neptune_hip_apply_builtin(p->body, &g, in, out, compute_stream, cfg);
+  auto launch_on = [&](const neptune_hip_apply_geom_t& g, void* st) {
+    return p->fn ? p->fn(&g, in, out, st, cfg) : neptune_hip_apply_builtin(p->body, &g, in, out, st, cfg);
   };
+  auto launch = [&](const neptune_hip_apply_geom_t& g) { return launch_on(g, compute_stream); };
   if (p->r_lo == 0 && p->r_hi == 0) return launch(p->whole);
   const slab::Plan::StepEvents* ev = p->timing ? &p->tev[p->timed_steps % slab::Plan::kTimingRing] : nullptr;
   // 1. the exchange, on the communication stream, once the input is complete on the compute stream
@@ -324,11 +327,23 @@ int neptune_hip_slab_apply(neptune_hip_slab_plan_t* p, const void* const* in, vo
     if (rc != NEPTUNE_HIP_OK) return rc;
   }
   if (ev) NEPTUNE_HIP_TRY(p->comm, hipEventRecord(ev->i1, cs));
-  // 3. edge planes once the ghosts have landed
-  NEPTUNE_HIP_TRY(p->comm, hipStreamWaitEvent(cs, p->halo_done, 0));
-  for (int e = 0; e < p->n_edges; ++e) {
-    const int rc = launch(p->edges[e]);
-    if (rc != NEPTUNE_HIP_OK) return rc;
+  // 3. edge planes once the ghosts have landed.  With overlap they are launched on the COMMUNICATION stream, right behind the
+  //    exchange: they read the input and write planes of their own, so they need not wait for the interior launch -- their
+  //    workgroups take the CUs the interior's last workgroups leave (a launch ends over ~5 % of its duration,
+  //    profiles/r03_timeline.txt) instead of starting one after the other behind it.  The compute stream joins at the end.
+  if (overlap && p->n_edges > 0 && !slab::edges_on_compute_stream()) {
+    for (int e = 0; e < p->n_edges; ++e) {
+      const int rc = launch_on(p->edges[e], p->comm_stream);
+      if (rc != NEPTUNE_HIP_OK) return rc;
+    }
+    NEPTUNE_HIP_TRY(p->comm, hipEventRecord(p->edges_done, p->comm_stream));
+    NEPTUNE_HIP_TRY(p->comm, hipStreamWaitEvent(cs, p->edges_done, 0));
+  } else {
+    NEPTUNE_HIP_TRY(p->comm, hipStreamWaitEvent(cs, p->halo_done, 0));
+    for (int e = 0; e < p->n_edges; ++e) {
+      const int rc = launch(p->edges[e]);
+      if (rc != NEPTUNE_HIP_OK) return rc;
+    }
   }
   if (ev) {
     NEPTUNE_HIP_TRY(p->comm, hipEventRecord(ev->e1, cs));

@@ -249,7 +249,7 @@ struct Plan {
   neptune_hip_launch_cfg_t cfg{0, -1, 0, 0};
   bool has_cfg = false;
   hipStream_t comm_stream = nullptr;   // created with the greatest priority: the exchange is dispatched ahead of the CU-filling interior grid
-  hipEvent_t ready = nullptr, halo_done = nullptr;
+  hipEvent_t ready = nullptr, halo_done = nullptr, edges_done = nullptr;
   // optional per-step timing (neptune_hip_slab_plan_timing): a ring of timed events, read back without a sync per step
   static constexpr int kTimingRing = 64;
   struct StepEvents { hipEvent_t x0, x1, i0, i1, e1; };
@@ -257,6 +257,13 @@ struct Plan {
   int64_t timed_steps = 0;
   StepEvents* tev = nullptr;           // kTimingRing sets, created when timing is first switched on
 };
+
+// NEPTUNE_HIP_EDGES=compute keeps the edge launches of a sharded step on the compute stream, behind the interior launch (the
+// schedule of rounds 1-2; measurements).  Default: on the communication stream, behind the exchange (neptune_hip_slab_apply).
+inline bool edges_on_compute_stream() {
+  static const bool v = [] { const char* e = getenv("NEPTUNE_HIP_EDGES"); return e && !strcmp(e, "compute"); }();
+  return v;
+}
 
 }  // namespace slab
 }  // namespace neptune_hip
