@@ -299,9 +299,12 @@ struct TileFor {
   static constexpr bool canon = pln && !PLN;
   static constexpr int wj = flat ? 8 : canon ? (WJ * WK <= 4 ? 4 : 8) : WJ, wk = (canon || flat) ? 1 : WK, rj = (canon || flat) ? 4 : RJ;
   static constexpr int rows = !pln ? march_rows<FP, RANK>(RJ) : flat ? tile2_rows<T, FP>(rj, wj, wk) : star ? plane_rows<T, FP>(rj, wj, wk) : planes_rows<T, FP>(rj, wj, wk);
+  // several inputs read at offsets on the plane-in-LDS kernel: two planes in flight per input (radius-4 pair 512^3: 2.33 TB/s
+  // against 1.93 with one; profiles/r03_highorder_tiles.txt)
+  static constexpr int pf_star = (pln && !flat && star && popcount_u(FP::HALO_MASK) >= 2) ? 2 : 1;
   using type = std::conditional_t<flat, Tile<rows, 8, 1, true, true, 1, false, true, true, true, 1, true>,
-               std::conditional_t<canon, Tile<rows, wj, 1, true, true, 1, false, true, false, true, 1, true>,
-                                  Tile<rows, WJ, WK, DPP, NT, PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>>>;
+               std::conditional_t<canon, Tile<rows, wj, 1, true, true, pf_star, false, true, false, true, 1, true>,
+                                  Tile<rows, WJ, WK, DPP, NT, (pln && PF < pf_star) ? pf_star : PF, NTL, LDSJ, (JK) && RANK == 2, JHL, KD, pln>>>;
 };
 // star footprints: the centre plane in LDS, the ring of own cells in registers; box footprints: every live plane in LDS
 template <class Body, class T, int RANK, int NIN, class FP, class TL>
