@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void neptune_apply_nd(NdParams<T, NIN> P, Body
   }
   const T through = P.in[0][o];  // copy-through: physical-index-wise (DataflowLowering.cpp:283-287)
   const T val = body(acc);
-  P.out[o] = inside ? val : OutsideOf<Body, T>::apply(body, through);
+  // (non-temporal: the result is not read again by this launch, and keeping it out of L2 leaves the neighbours' lines there --
+  //  rows form 1024^3 7-point 2.52 -> 2.84 TB/s)
+  __builtin_nontemporal_store(inside ? val : OutsideOf<Body, T>::apply(body, through), P.out + o);
 }
 
 }  // namespace neptune_hip
