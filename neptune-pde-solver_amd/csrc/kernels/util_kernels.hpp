@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void neptune_store_box(const T* __restrict__ s
   const T* s = src + ((i + P.soff[0]) * P.sshape[1] + (j + P.soff[1])) * P.sshape[2] + (k0 + P.soff[2]);
   T* d = dst + ((i + P.doff[0]) * P.dshape[1] + (j + P.doff[1])) * P.dshape[2] + (k0 + P.doff[2]);
   if (k0 + VK <= P.ext[2]) {
-    *reinterpret_cast<uvec*>(d) = *reinterpret_cast<const uvec*>(s);
+    __builtin_nontemporal_store(*reinterpret_cast<const uvec*>(s), reinterpret_cast<uvec*>(d));
   } else {
     for (int e = 0; k0 + e < P.ext[2]; ++e) d[e] = s[e];
   }
