@@ -317,7 +317,9 @@ int neptune_hip_slab_apply(neptune_hip_slab_plan_t* p, const void* const* in, vo
                                        p->peer_hi, p->comm_stream);
     if (rc != NEPTUNE_HIP_OK) return rc;
   }
-  NEPTUNE_HIP_TRY(p->comm, hipEventRecord(p->halo_done, p->comm_stream));
+  // (with the edge launches on the communication stream nobody waits for the exchange alone: one event less per step)
+  const bool edges_on_comm = overlap && p->n_edges > 0 && !slab::edges_on_compute_stream();
+  if (!edges_on_comm) NEPTUNE_HIP_TRY(p->comm, hipEventRecord(p->halo_done, p->comm_stream));
   if (ev) NEPTUNE_HIP_TRY(p->comm, hipEventRecord(ev->x1, p->comm_stream));
   if (!overlap) NEPTUNE_HIP_TRY(p->comm, hipStreamWaitEvent(cs, p->halo_done, 0));
   // 2. interior planes overlap the exchange
@@ -331,7 +333,7 @@ int neptune_hip_slab_apply(neptune_hip_slab_plan_t* p, const void* const* in, vo
   //    exchange: they read the input and write planes of their own, so they need not wait for the interior launch -- their
   //    workgroups take the CUs the interior's last workgroups leave (a launch ends over ~5 % of its duration,
   //    profiles/r03_timeline.txt) instead of starting one after the other behind it.  The compute stream joins at the end.
-  if (overlap && p->n_edges > 0 && !slab::edges_on_compute_stream()) {
+  if (edges_on_comm) {
     for (int e = 0; e < p->n_edges; ++e) {
       const int rc = launch_on(p->edges[e], p->comm_stream);
       if (rc != NEPTUNE_HIP_OK) return rc;
